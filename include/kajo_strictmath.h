@@ -1,0 +1,258 @@
+/*
+ * kajo_strictmath.h -- elementary functions of the STRICT numerics mode (interface contract).
+ *
+ * The reference calls libm's sinf/cosf/asinf/acosf/powf (renderer/cpu/Random.cpp:77-102,
+ * renderer/cpu/Light.cpp:26-49, renderer/cpu/BSDF.cpp:61-74, renderer/Image.cpp:14-17).
+ * glibc's results cannot be reproduced bit for bit by a GPU's math library, and one
+ * flipped branch changes a whole path, so "does the GPU integrator
+ * take exactly the decisions the CPU integrator takes" is only testable when both sides
+ * evaluate these five functions with the same arithmetic. This header is that arithmetic:
+ * range reduction + truncated series in IEEE binary64 using only + - * / sqrt floor and
+ * integer bit moves, rounded once to binary32 at the end. Compiled with FP contraction off
+ * it yields identical bits from g++ on x86-64 and from hipcc on gfx950; its error before
+ * the final rounding is < 1e-11 relative, i.e. the float result equals the correctly rounded
+ * one except within ~1e-4 of a rounding boundary (tests/test_strictmath.py pins it against
+ * libm to <= 1 ulp).
+ *
+ * sqrtf and the four basic operations need no counterpart: they are correctly rounded on
+ * both targets (hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt).
+ *
+ * Plain C subset; no state; every function is pure.
+ */
+#ifndef KAJO_STRICTMATH_H
+#define KAJO_STRICTMATH_H
+
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define KSM_FN __host__ __device__ static inline
+#else
+#define KSM_FN static inline
+#endif
+
+KSM_FN uint64_t ksm_bits(double d)
+{
+    uint64_t u;
+    __builtin_memcpy(&u, &d, 8);
+    return u;
+}
+
+KSM_FN double ksm_from_bits(uint64_t u)
+{
+    double d;
+    __builtin_memcpy(&d, &u, 8);
+    return d;
+}
+
+/* 2^e for e in [-1022, 1023] */
+KSM_FN double ksm_pow2(int e)
+{
+    return ksm_from_bits((uint64_t)(e + 1023) << 52);
+}
+
+/* sin r, |r| <= pi/4 (Taylor to r^19, truncation < 1e-19) */
+KSM_FN double ksm_sin_kernel(double r)
+{
+    double z = r * r;
+    double p = -0x1.2f49b46814157p-57;
+    p = p * z + 0x1.952c77030ad4ap-49;
+    p = p * z + -0x1.ae7f3e733b81fp-41;
+    p = p * z + 0x1.6124613a86d09p-33;
+    p = p * z + -0x1.ae64567f544e4p-26;
+    p = p * z + 0x1.71de3a556c734p-19;
+    p = p * z + -0x1.a01a01a01a01ap-13;
+    p = p * z + 0x1.1111111111111p-7;
+    p = p * z + -0x1.5555555555555p-3;
+    return r + r * (z * p);
+}
+
+/* cos r, |r| <= pi/4 (Taylor to r^20) */
+KSM_FN double ksm_cos_kernel(double r)
+{
+    double z = r * r;
+    double p = 0x1.e542ba4020225p-62;
+    p = p * z + -0x1.6827863b97d97p-53;
+    p = p * z + 0x1.ae7f3e733b81fp-45;
+    p = p * z + -0x1.93974a8c07c9dp-37;
+    p = p * z + 0x1.1eed8eff8d898p-29;
+    p = p * z + -0x1.27e4fb7789f5cp-22;
+    p = p * z + 0x1.a01a01a01a01ap-16;
+    p = p * z + -0x1.6c16c16c16c17p-10;
+    p = p * z + 0x1.5555555555555p-5;
+    p = p * z + -0x1.0000000000000p-1;
+    return 1.0 + z * p;
+}
+
+/* Cody-Waite reduction by pi/2: x = k*pi/2 + r, |r| <= pi/4 (+eps); valid for |x| < 2^20 */
+KSM_FN double ksm_reduce_pio2(double x, int* quadrant)
+{
+    double k = __builtin_floor(x * 0x1.45f306dc9c883p-1 + 0.5);
+    double r = (x - k * 0x1.921fb54400000p+0) - k * 0x1.0b4611a626331p-34;
+    *quadrant = (int)((long long)k & 3);
+    return r;
+}
+
+KSM_FN float kajo_sinf(float xf)
+{
+    double x = (double)xf;
+    if (!(__builtin_fabs(x) < 1048576.0))
+        return (float)(x - x); /* NaN for NaN/inf/huge: never produced by the integrator */
+    int q;
+    double r = ksm_reduce_pio2(x, &q);
+    double s = ksm_sin_kernel(r);
+    double c = ksm_cos_kernel(r);
+    double v = (q & 1) ? c : s;
+    return (float)((q & 2) ? -v : v);
+}
+
+KSM_FN float kajo_cosf(float xf)
+{
+    double x = (double)xf;
+    if (!(__builtin_fabs(x) < 1048576.0))
+        return (float)(x - x);
+    int q;
+    double r = ksm_reduce_pio2(x, &q);
+    double s = ksm_sin_kernel(r);
+    double c = ksm_cos_kernel(r);
+    double v = (q & 1) ? s : c;
+    return (float)(((q + 1) & 2) ? -v : v);
+}
+
+/* asin x for |x| <= 0.5 (Taylor to x^35, truncation < 2e-13 relative) */
+KSM_FN double ksm_asin_kernel(double x)
+{
+    double z = x * x;
+    double p = 0x1.fcaf8fb6db6dbp-9;
+    p = p * z + 0x1.15ee9d45d1746p-8;
+    p = p * z + 0x1.31683bdef7bdfp-8;
+    p = p * z + 0x1.51ba308d3dcb1p-8;
+    p = p * z + 0x1.782dda12f684cp-8;
+    p = p * z + 0x1.a6863d70a3d71p-8;
+    p = p * z + 0x1.df3bd37a6f4dfp-8;
+    p = p * z + 0x1.12ef3cf3cf3cfp-7;
+    p = p * z + 0x1.3fde50d79435ep-7;
+    p = p * z + 0x1.7a87878787878p-7;
+    p = p * z + 0x1.c99999999999ap-7;
+    p = p * z + 0x1.1c4ec4ec4ec4fp-6;
+    p = p * z + 0x1.6e8ba2e8ba2e9p-6;
+    p = p * z + 0x1.f1c71c71c71c7p-6;
+    p = p * z + 0x1.6db6db6db6db7p-5;
+    p = p * z + 0x1.3333333333333p-4;
+    p = p * z + 0x1.5555555555555p-3;
+    return x + x * (z * p);
+}
+
+#define KSM_PIO2 0x1.921fb54442d18p+0
+#define KSM_PI 0x1.921fb54442d18p+1
+
+KSM_FN double ksm_asin(double x)
+{
+    double a = __builtin_fabs(x);
+    if (a <= 0.5)
+        return ksm_asin_kernel(x);
+    /* |x| > 1 gives sqrt(negative) = NaN; NaN input lands here too and stays NaN */
+    double s = __builtin_sqrt((1.0 - a) * 0.5);
+    double r = KSM_PIO2 - 2.0 * ksm_asin_kernel(s);
+    return x < 0.0 ? -r : r;
+}
+
+KSM_FN float kajo_asinf(float x)
+{
+    return (float)ksm_asin((double)x);
+}
+
+KSM_FN float kajo_acosf(float xf)
+{
+    double x = (double)xf;
+    double a = __builtin_fabs(x);
+    if (a <= 0.5)
+        return (float)(KSM_PIO2 - ksm_asin_kernel(x));
+    double s = __builtin_sqrt((1.0 - a) * 0.5);
+    double t = 2.0 * ksm_asin_kernel(s);
+    return (float)(x < 0.0 ? KSM_PI - t : t);
+}
+
+/* natural log of a positive, normal double */
+KSM_FN double ksm_log(double x)
+{
+    uint64_t b = ksm_bits(x);
+    int e = (int)((b >> 52) & 0x7ff) - 1023;
+    uint64_t mb = (b & 0x000fffffffffffffull) | 0x3ff0000000000000ull;
+    double m = ksm_from_bits(mb);
+    if (m > 0x1.6a09e667f3bcdp+0) { /* sqrt 2 */
+        m = m * 0.5;
+        e = e + 1;
+    }
+    double f = m - 1.0;
+    double s = f / (2.0 + f);
+    double z = s * s;
+    double p = 0x1.642c8590b2164p-4;
+    p = p * z + 0x1.8618618618618p-4;
+    p = p * z + 0x1.af286bca1af28p-4;
+    p = p * z + 0x1.e1e1e1e1e1e1ep-4;
+    p = p * z + 0x1.1111111111111p-3;
+    p = p * z + 0x1.3b13b13b13b14p-3;
+    p = p * z + 0x1.745d1745d1746p-3;
+    p = p * z + 0x1.c71c71c71c71cp-3;
+    p = p * z + 0x1.2492492492492p-2;
+    p = p * z + 0x1.999999999999ap-2;
+    p = p * z + 0x1.5555555555555p-1;
+    p = p * z + 0x1.0000000000000p+1;
+    double de = (double)e;
+    return de * 0x1.62e42fef00000p-1 + (de * 0x1.473de6af278edp-34 + s * p);
+}
+
+/* e^t, finite t */
+KSM_FN double ksm_exp(double t)
+{
+    if (t > 709.0)
+        return ksm_from_bits(0x7ff0000000000000ull);
+    if (t < -745.0)
+        return 0.0;
+    double k = __builtin_floor(t * 0x1.71547652b82fep+0 + 0.5);
+    double r = (t - k * 0x1.62e42fef00000p-1) - k * 0x1.473de6af278edp-34;
+    double p = 0x1.93974a8c07c9dp-37;
+    p = p * r + 0x1.6124613a86d09p-33;
+    p = p * r + 0x1.1eed8eff8d898p-29;
+    p = p * r + 0x1.ae64567f544e4p-26;
+    p = p * r + 0x1.27e4fb7789f5cp-22;
+    p = p * r + 0x1.71de3a556c734p-19;
+    p = p * r + 0x1.a01a01a01a01ap-16;
+    p = p * r + 0x1.a01a01a01a01ap-13;
+    p = p * r + 0x1.6c16c16c16c17p-10;
+    p = p * r + 0x1.1111111111111p-7;
+    p = p * r + 0x1.5555555555555p-5;
+    p = p * r + 0x1.5555555555555p-3;
+    p = p * r + 0x1.0000000000000p-1;
+    p = p * r + 1.0;
+    p = p * r + 1.0;
+    int ki = (int)k;
+    int k1 = ki >> 1;
+    int k2 = ki - k1;
+    return (p * ksm_pow2(k1)) * ksm_pow2(k2);
+}
+
+/*
+ * powf for the domain the integrator uses: x >= 0 (a clamped cosine, a uniform variate or
+ * a clamped colour), any finite y. x < 0 or NaN operands give NaN; pow(0, 0) = 1,
+ * pow(0, y > 0) = 0, pow(0, y < 0) = inf; pow(x, 0) = 1; pow(1, y) = 1; pow(inf, .) is not
+ * special-cased beyond what exp(y log x) yields.
+ */
+KSM_FN float kajo_powf(float xf, float yf)
+{
+    double x = (double)xf;
+    double y = (double)yf;
+    if (!(x == x) || !(y == y))
+        return (float)(x + y);
+    if (y == 0.0)
+        return 1.0f;
+    if (x < 0.0)
+        return (float)__builtin_sqrt(x); /* NaN */
+    if (x == 0.0)
+        return y > 0.0 ? 0.0f : (float)ksm_from_bits(0x7ff0000000000000ull);
+    if (x == ksm_from_bits(0x7ff0000000000000ull))
+        return y > 0.0 ? (float)x : 0.0f;
+    return (float)ksm_exp(y * ksm_log(x));
+}
+
+#endif /* KAJO_STRICTMATH_H */

@@ -1,0 +1,132 @@
+/*
+ * kajo_hip.h -- C ABI of the MI355X rendering backend for Kajo (libkajo_hip.so).
+ *
+ * This is the drop-in boundary for ONE path of the reference: the per-pixel Monte-Carlo
+ * integrator that cpu::Scheduler::run() drives through cpu::Renderer::render()
+ * (renderer/cpu/Scheduler.cpp:60-85, renderer/cpu/Renderer.cpp:25-81). A backend in the
+ * reference is a class with the constructor (const scene::Scene&, Image*, Preview*) and one
+ * method run() (renderer/Scheduler.h:12-16, selected by name in renderer/Main.cpp:135-142);
+ * kajo_amd/host/HipScheduler.{h,cpp} is that class for "-r hip", and everything it needs from
+ * the GPU goes through the entry points below: plain pointers and sizes, int error codes, no
+ * C++ / HIP / torch types in any signature.
+ *
+ * What each entry point replaces in the reference:
+ *   kajo_hip_create          cpu::Renderer::Renderer + cpu::Scene::Scene (Renderer.cpp:17-23,
+ *                            cpu/Scene.cpp:9-38): copy the scene, stage inverse matrices and
+ *                            determinants, camera basis of Renderer.cpp:29-34
+ *   kajo_hip_render          the pass loop of cpu::Renderer::render (Renderer.cpp:44-72) for
+ *                            every pixel this handle owns, `passes` more passes, asynchronous
+ *   kajo_hip_wait            joinTasks (cpu/Scheduler.cpp:44-51)
+ *   kajo_hip_resolve_argb8   Renderer.cpp:73-75 + Image::linearToSRGB/colorToRGBA8
+ *                            (renderer/Image.cpp:14-27) into Image::pixels (Image.h:18-20)
+ *   kajo_hip_read_radiance   the radianceMap local of Renderer.cpp:36 (not observable in the
+ *                            reference; exported here for parity tests)
+ *   kajo_hip_counters        the samples/s bookkeeping of Preview::update (Preview.cpp:79-98)
+ *   kajo_hip_destroy         the unique_ptr members of cpu::Scheduler (cpu/Scheduler.h:29-31)
+ *
+ * Pixels are dealt to GPUs as fixed-size tiles: a handle created with
+ * (tileIndex, tileCount) accumulates the tiles t with t % tileCount == tileIndex in a compact
+ * device buffer; kajo_hip_tile_buffer exposes it for the one RCCL gather per frame that the
+ * host performs (torch.distributed or rccl directly), kajo_hip_compose places the gathered
+ * buffers into the whole frame on the root handle. Every camera path draws from its own RNG
+ * stream (include/kajo_stream.h), so the frame is bit-identical for any tiling / GPU count.
+ *
+ * Threading: a handle is not re-entrant; distinct handles are independent (section 8b).
+ * All calls return 0 on success or a negative KAJO_E_* code; kajo_hip_last_error() gives the
+ * message of the calling thread's most recent failure. No exception crosses this boundary.
+ */
+#ifndef KAJO_HIP_H
+#define KAJO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "kajo_scene.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KAJO_OK 0
+#define KAJO_E_INVALID (-1)   /* bad argument */
+#define KAJO_E_HIP (-2)       /* a HIP runtime call failed (message has the HIP error) */
+#define KAJO_E_NO_DEVICE (-3) /* no usable GPU: the backend never falls back to the CPU */
+#define KAJO_E_STATE (-4)     /* call not valid in the handle's current state */
+
+/* KajoParams.flags */
+#define KAJO_FLAG_STRICT 1u   /* strict numerics: bit-identical to the CPU oracle (slower) */
+#define KAJO_FLAG_COUNTERS 2u /* maintain device-side work counters */
+
+typedef struct KajoParams {
+    int32_t samplesPerPass; /* S: nominal samples per pixel per pass (reference: 32, Renderer.cpp:21);
+                               n = floor(sqrt(S)) strata per axis are traced, the sum is divided by S */
+    int32_t depthLimit;     /* reference: 8 (Shader.cpp:24) */
+    uint64_t seed;          /* stream seed (reference constant 0715517 = 236367, Random.h:43) */
+    uint32_t flags;         /* KAJO_FLAG_* */
+    int32_t device;         /* HIP device ordinal */
+    int32_t tileW, tileH;   /* tile size in pixels; multiples of 8; 0 => 64 x 16 */
+    int32_t tileIndex;      /* this handle renders tiles t with t % tileCount == tileIndex */
+    int32_t tileCount;      /* number of handles sharing the frame (GPUs); 0 => 1 */
+    int32_t passesPerLaunch; /* passes fused into one kernel launch; 0 => library default */
+} KajoParams;
+
+typedef struct KajoCounters {
+    uint64_t passes;         /* passes rendered so far */
+    uint64_t paths;          /* camera paths traced = pixels * n^2 * passes */
+    uint64_t traversals;     /* closest-hit scene walks (device counter; 0 without KAJO_FLAG_COUNTERS) */
+    uint64_t vertices;       /* shaded path vertices (device counter) */
+    uint64_t primitiveTests; /* traversals * (nPlanes + nSpheres) */
+    uint64_t laneSlots;      /* 64 * wave-iterations of the trace loop: traversals / laneSlots = lane efficiency */
+    double kernelMs;         /* summed device time of the render kernels (HIP events on the handle's stream) */
+    uint64_t launches;       /* render kernel launches */
+} KajoCounters;
+
+typedef struct KajoHip* kajo_hip_t;
+
+/* Fills *p with the reference's constants: S = 32, depth 8, seed 236367, one tile set. */
+void kajo_hip_default_params(KajoParams* p);
+
+int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoParams* params, kajo_hip_t* out);
+int kajo_hip_destroy(kajo_hip_t h); /* NULL is accepted */
+
+/* Enqueue `passes` more passes (pass numbers continue from the handle's count, first = 1). */
+int kajo_hip_render(kajo_hip_t h, int passes);
+int kajo_hip_wait(kajo_hip_t h);
+/* Zero the accumulation and restart the pass numbering at 1. */
+int kajo_hip_reset(kajo_hip_t h);
+
+/* Whole-frame outputs; valid when tileCount == 1, or on a handle that has been composed.
+   dst are HOST pointers: width*height uint32 ARGB8 (row 0 = top) / width*height*4 floats
+   (sum over passes of radiance / S; divide by the pass count for the estimate). They wait for
+   outstanding passes. */
+int kajo_hip_resolve_argb8(kajo_hip_t h, uint32_t* dst);
+int kajo_hip_read_radiance(kajo_hip_t h, float* dst);
+/* Same, into DEVICE memory (e.g. a mapped preview buffer), asynchronous on the handle's stream. */
+int kajo_hip_resolve_argb8_device(kajo_hip_t h, void* dst);
+
+/* Multi-GPU plumbing. The tile buffer is ceil(T / tileCount) tiles of tileW*tileH float4 each
+   (T = tiles in the frame), identical size on every rank so that one gather moves it. */
+int kajo_hip_tile_buffer(kajo_hip_t h, void** devicePtr, size_t* bytes);
+/* gathered = DEVICE pointer to tileCount consecutive tile buffers in rank order (what a gather
+   to this rank produced); composes them into this handle's whole-frame buffer. With
+   tileCount == 1 composition happens implicitly. */
+int kajo_hip_compose(kajo_hip_t h, const void* gathered);
+
+/* Use an existing HIP stream (hipStream_t passed as void*) instead of the handle's own. */
+int kajo_hip_set_stream(kajo_hip_t h, void* stream);
+
+int kajo_hip_counters(kajo_hip_t h, KajoCounters* out);
+
+/* Host-only helper (no GPU needed): what create() stages from a scene -- inverse(16) +
+   determinant per object, planes first then spheres, 17 floats each (cpu/Scene.cpp:9-13) and
+   the camera basis p1, p2, p3, origin (Renderer.cpp:30-34), 12 floats. For tests. */
+int kajo_hip_stage_scene(const KajoScene* scene, float* invDet17, float* basis12);
+
+const char* kajo_hip_last_error(void);
+const char* kajo_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* KAJO_HIP_H */

@@ -1,0 +1,100 @@
+"""ctypes binding of libkajo_hip.so (include/kajo_hip.h). Host plumbing only.
+
+The library is the product's compute path; there is no Python or CPU fallback: a missing or
+unloadable library raises ImportError, a missing GPU makes kajo_hip_create fail.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+# PyTorch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so, soname
+# libamdhip64.so.7). Two HIP runtimes in one process do not share the GPU, so torch must be
+# imported BEFORE libkajo_hip.so: the dynamic loader then satisfies the library's
+# libamdhip64.so.7 dependency with the copy torch already mapped, and both use one runtime.
+import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed)
+
+from .scene import KajoScene
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libkajo_hip.so")
+
+KAJO_FLAG_STRICT = 1
+KAJO_FLAG_COUNTERS = 2
+
+# every symbol include/kajo_hip.h declares
+EXPORTS = [
+    "kajo_hip_default_params", "kajo_hip_create", "kajo_hip_destroy", "kajo_hip_render", "kajo_hip_wait",
+    "kajo_hip_reset", "kajo_hip_resolve_argb8", "kajo_hip_read_radiance", "kajo_hip_resolve_argb8_device",
+    "kajo_hip_tile_buffer", "kajo_hip_compose", "kajo_hip_set_stream", "kajo_hip_counters",
+    "kajo_hip_stage_scene", "kajo_hip_last_error", "kajo_hip_version",
+]
+
+
+class KajoParams(C.Structure):
+    _fields_ = [
+        ("samplesPerPass", C.c_int32),
+        ("depthLimit", C.c_int32),
+        ("seed", C.c_uint64),
+        ("flags", C.c_uint32),
+        ("device", C.c_int32),
+        ("tileW", C.c_int32),
+        ("tileH", C.c_int32),
+        ("tileIndex", C.c_int32),
+        ("tileCount", C.c_int32),
+        ("passesPerLaunch", C.c_int32),
+    ]
+
+
+class KajoCounters(C.Structure):
+    _fields_ = [
+        ("passes", C.c_uint64),
+        ("paths", C.c_uint64),
+        ("traversals", C.c_uint64),
+        ("vertices", C.c_uint64),
+        ("primitiveTests", C.c_uint64),
+        ("laneSlots", C.c_uint64),
+        ("kernelMs", C.c_double),
+        ("launches", C.c_uint64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C kajo_amd/csrc)" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.kajo_hip_last_error.restype = C.c_char_p
+        L.kajo_hip_version.restype = C.c_char_p
+        L.kajo_hip_create.argtypes = [C.POINTER(KajoScene), C.c_int, C.c_int, C.POINTER(KajoParams), C.POINTER(C.c_void_p)]
+        L.kajo_hip_destroy.argtypes = [C.c_void_p]
+        L.kajo_hip_render.argtypes = [C.c_void_p, C.c_int]
+        L.kajo_hip_wait.argtypes = [C.c_void_p]
+        L.kajo_hip_reset.argtypes = [C.c_void_p]
+        L.kajo_hip_resolve_argb8.argtypes = [C.c_void_p, C.c_void_p]
+        L.kajo_hip_read_radiance.argtypes = [C.c_void_p, C.c_void_p]
+        L.kajo_hip_resolve_argb8_device.argtypes = [C.c_void_p, C.c_void_p]
+        L.kajo_hip_tile_buffer.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        L.kajo_hip_compose.argtypes = [C.c_void_p, C.c_void_p]
+        L.kajo_hip_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+        L.kajo_hip_counters.argtypes = [C.c_void_p, C.POINTER(KajoCounters)]
+        L.kajo_hip_stage_scene.argtypes = [C.POINTER(KajoScene), C.c_void_p, C.c_void_p]
+        L.kajo_hip_default_params.argtypes = [C.POINTER(KajoParams)]
+        _lib = L
+    return _lib
+
+
+class KajoError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("kajo_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+def check(rc):
+    if rc != 0:
+        raise KajoError(rc, (lib().kajo_hip_last_error() or b"").decode())

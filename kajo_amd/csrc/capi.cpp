@@ -1,0 +1,562 @@
+// capi.cpp -- libkajo_hip.so: the C ABI of include/kajo_hip.h over the HIP runtime.
+//
+// One KajoHip handle = one GPU's share of a frame: the staged scene in device memory, the
+// compact tile accumulation buffer, a stream, and (on demand) the composed whole frame and
+// its ARGB8 image. There is NO CPU rendering path in this library: without a usable HIP
+// device kajo_hip_create fails with KAJO_E_NO_DEVICE.
+#include "kajo_hip.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "render_args.h"
+#include "stage.h"
+
+// launchers defined next to their kernels (kernel_fast.hip, kernel_strict.hip, aux_kernels.hip)
+extern "C" {
+int kajo_render_fast_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
+int kajo_render_strict_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
+int kajo_render_fast_set_lds(size_t lds);
+int kajo_render_strict_set_lds(size_t lds);
+int kajo_resolve_fast_launch(const void* frame, int count, float passes, void* dst, void* stream);
+int kajo_resolve_strict_launch(const void* frame, int count, float passes, void* dst, void* stream);
+int kajo_compose_launch(const void* gathered, const TileMap* map, void* frame, void* stream);
+}
+
+namespace
+{
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& what)
+{
+    g_error = what;
+    return code;
+}
+
+int failHip(hipError_t e, const char* what)
+{
+    return fail(KAJO_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIP_TRY(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess)                                                                                          \
+            return failHip(e_, #expr);                                                                                 \
+    } while (0)
+
+template <class T>
+hipError_t upload(const std::vector<T>& v, const T** out, std::vector<void*>& owned)
+{
+    *out = nullptr;
+    const size_t bytes = (v.empty() ? 1 : v.size()) * sizeof(T);
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+        return e;
+    owned.push_back(p);
+    if (!v.empty()) {
+        e = hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess)
+            return e;
+    }
+    *out = static_cast<const T*>(p);
+    return hipSuccess;
+}
+
+} // namespace
+
+struct KajoHip
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    int W = 0, H = 0;
+    KajoParams params{};
+    kajo::StagedScene staged;
+    DSceneView view{};
+    std::vector<void*> sceneBuffers;
+    TileMap map{};
+    int tilesY = 0, nTiles = 0, nTilesOwned = 0, tilesPerOwner = 0;
+    size_t tileBytes = 0;
+    void* tiles = nullptr;   // float4[slotsPerOwner]
+    void* frame = nullptr;   // float4[W*H], lazily
+    void* argb = nullptr;    // uint32[W*H], lazily
+    bool frameValid = false;
+    unsigned long long* counters = nullptr; // device [4]
+    int passesDone = 0;
+    size_t ldsBytes = 0;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // kernel timing
+    std::vector<hipEvent_t> eventPool;
+    double kernelMs = 0.0;
+    uint64_t launches = 0;
+
+    bool strict() const { return params.flags & KAJO_FLAG_STRICT; }
+};
+
+namespace
+{
+
+int bind(KajoHip* h)
+{
+    HIP_TRY(hipSetDevice(h->device));
+    return KAJO_OK;
+}
+
+int drainEvents(KajoHip* h)
+{
+    for (auto& pr : h->pending) {
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+        h->kernelMs += ms;
+        h->eventPool.push_back(pr.first);
+        h->eventPool.push_back(pr.second);
+    }
+    h->pending.clear();
+    return KAJO_OK;
+}
+
+int getEvent(KajoHip* h, hipEvent_t* ev)
+{
+    if (!h->eventPool.empty()) {
+        *ev = h->eventPool.back();
+        h->eventPool.pop_back();
+        return KAJO_OK;
+    }
+    HIP_TRY(hipEventCreate(ev));
+    return KAJO_OK;
+}
+
+int ensureFrame(KajoHip* h)
+{
+    if (!h->frame)
+        HIP_TRY(hipMalloc(&h->frame, (size_t)h->W * h->H * 16));
+    return KAJO_OK;
+}
+
+// whole frame from this handle's own tiles (single-owner case)
+int composeOwn(KajoHip* h)
+{
+    if (h->frameValid)
+        return KAJO_OK;
+    if (h->map.tileCount != 1)
+        return fail(KAJO_E_STATE, "whole-frame output needs kajo_hip_compose() when tileCount > 1");
+    int rc = ensureFrame(h);
+    if (rc)
+        return rc;
+    HIP_TRY((hipError_t)kajo_compose_launch(h->tiles, &h->map, h->frame, h->stream));
+    h->frameValid = true;
+    return KAJO_OK;
+}
+
+void destroy(KajoHip* h)
+{
+    if (!h)
+        return;
+    hipSetDevice(h->device);
+    if (h->stream)
+        hipStreamSynchronize(h->stream);
+    for (auto& pr : h->pending) {
+        hipEventDestroy(pr.first);
+        hipEventDestroy(pr.second);
+    }
+    for (hipEvent_t e : h->eventPool)
+        hipEventDestroy(e);
+    for (void* p : h->sceneBuffers)
+        hipFree(p);
+    if (h->tiles)
+        hipFree(h->tiles);
+    if (h->frame)
+        hipFree(h->frame);
+    if (h->argb)
+        hipFree(h->argb);
+    if (h->counters)
+        hipFree(h->counters);
+    if (h->ownStream && h->stream)
+        hipStreamDestroy(h->stream);
+    delete h;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* kajo_hip_last_error(void)
+{
+    return g_error.c_str();
+}
+
+const char* kajo_hip_version(void)
+{
+    return "kajo-hip 0.1 (gfx950)";
+}
+
+void kajo_hip_default_params(KajoParams* p)
+{
+    std::memset(p, 0, sizeof *p);
+    p->samplesPerPass = 32;  // Renderer.cpp:21
+    p->depthLimit = 8;       // Shader.cpp:24
+    p->seed = 0715517;       // Random.h:43
+    p->tileW = 64;
+    p->tileH = 16;
+    p->tileIndex = 0;
+    p->tileCount = 1;
+    p->passesPerLaunch = 0;
+}
+
+int kajo_hip_stage_scene(const KajoScene* scene, float* invDet17, float* basis12)
+{
+    if (!scene)
+        return fail(KAJO_E_INVALID, "scene is null");
+    kajo::StagedScene st;
+    kajo::stageScene(*scene, st);
+    if (invDet17)
+        std::memcpy(invDet17, st.invDet.data(), st.invDet.size() * sizeof(float));
+    if (basis12) {
+        std::memcpy(basis12 + 0, st.p1, 12);
+        std::memcpy(basis12 + 3, st.p2, 12);
+        std::memcpy(basis12 + 6, st.p3, 12);
+        std::memcpy(basis12 + 9, st.origin, 12);
+    }
+    return KAJO_OK;
+}
+
+int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoParams* params, kajo_hip_t* out)
+{
+    if (!scene || !params || !out)
+        return fail(KAJO_E_INVALID, "null argument");
+    *out = nullptr;
+    if (width <= 0 || height <= 0 || (long long)width * height > (1ll << 31) - 1)
+        return fail(KAJO_E_INVALID, "image size out of range");
+    if (scene->nPlanes < 0 || scene->nSpheres < 0 || (scene->nPlanes && !scene->planes) || (scene->nSpheres && !scene->spheres))
+        return fail(KAJO_E_INVALID, "scene arrays inconsistent");
+    KajoParams p = *params;
+    if (p.tileW == 0)
+        p.tileW = 64;
+    if (p.tileH == 0)
+        p.tileH = 16;
+    if (p.tileCount == 0)
+        p.tileCount = 1;
+    if (p.samplesPerPass < 1 || p.samplesPerPass > 65535)
+        return fail(KAJO_E_INVALID, "samplesPerPass must be in [1, 65535]");
+    if (p.depthLimit < 0)
+        return fail(KAJO_E_INVALID, "depthLimit must be >= 0");
+    if (p.tileW < 8 || p.tileH < 8 || (p.tileW & 7) || (p.tileH & 7) || (p.tileW * p.tileH) % 256)
+        return fail(KAJO_E_INVALID, "tile size must be multiples of 8 with tileW*tileH a multiple of 256");
+    if (p.tileCount < 1 || p.tileIndex < 0 || p.tileIndex >= p.tileCount)
+        return fail(KAJO_E_INVALID, "tileIndex/tileCount out of range");
+
+    int nDev = 0;
+    hipError_t e = hipGetDeviceCount(&nDev);
+    if (e != hipSuccess || nDev <= 0)
+        return fail(KAJO_E_NO_DEVICE, "no HIP device available; this backend has no CPU path");
+    if (p.device < 0 || p.device >= nDev)
+        return fail(KAJO_E_INVALID, "device ordinal out of range");
+
+    KajoHip* h = new (std::nothrow) KajoHip;
+    if (!h)
+        return fail(KAJO_E_INVALID, "out of host memory");
+    h->device = p.device;
+    h->params = p;
+    h->W = width;
+    h->H = height;
+#define CREATE_TRY(expr)                                                                                               \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) {                                                                                        \
+            destroy(h);                                                                                                \
+            return failHip(e_, #expr);                                                                                 \
+        }                                                                                                              \
+    } while (0)
+    CREATE_TRY(hipSetDevice(h->device));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    h->ownStream = true;
+
+    // ---- scene -----------------------------------------------------------------------------
+    kajo::stageScene(*scene, h->staged);
+    const kajo::StagedScene& st = h->staged;
+    DSceneView& v = h->view;
+    CREATE_TRY(upload(st.planeRow, &v.planeRow, h->sceneBuffers));
+    CREATE_TRY(upload(st.planeDet, &v.planeDet, h->sceneBuffers));
+    CREATE_TRY(upload(st.planeFrame, &v.planeFrame, h->sceneBuffers));
+    CREATE_TRY(upload(st.sphereHot, &v.sphereHot, h->sceneBuffers));
+    CREATE_TRY(upload(st.sphereHotOffset, &v.sphereHotOffset, h->sceneBuffers));
+    CREATE_TRY(upload(st.sphereCold, &v.sphereCold, h->sceneBuffers));
+    CREATE_TRY(upload(st.material, &v.material, h->sceneBuffers));
+    CREATE_TRY(upload(st.light, &v.light, h->sceneBuffers));
+    v.nPlanes = st.nPlanes;
+    v.nSpheres = st.nSpheres;
+    v.nSphereHot = (int)st.sphereHot.size();
+    v.nLights = (int)st.light.size();
+    v.allTranslated = st.allTranslated;
+    for (int i = 0; i < 3; i++) {
+        v.background[i] = st.background[i];
+        v.p1[i] = st.p1[i];
+        v.dp2[i] = st.p2[i] - st.p1[i]; // (p2 - p1), (p3 - p1) of Renderer.cpp:58
+        v.dp3[i] = st.p3[i] - st.p1[i];
+        v.origin[i] = st.origin[i];
+    }
+    h->ldsBytes = (size_t)v.nPlanes * (16 + 4) + (size_t)v.nSphereHot * 16 + (size_t)v.nSpheres * 4;
+    if (h->ldsBytes > 160 * 1024) {
+        destroy(h);
+        return fail(KAJO_E_INVALID, "scene exceeds the 160 KiB LDS staging limit (hot records)");
+    }
+    if (h->ldsBytes > 48 * 1024) {
+        CREATE_TRY((hipError_t)(h->strict() ? kajo_render_strict_set_lds(h->ldsBytes) : kajo_render_fast_set_lds(h->ldsBytes)));
+    }
+
+    // ---- tiles -----------------------------------------------------------------------------
+    TileMap& m = h->map;
+    m.W = width;
+    m.H = height;
+    m.tileW = p.tileW;
+    m.tileH = p.tileH;
+    m.tilesX = (width + p.tileW - 1) / p.tileW;
+    m.tileCount = p.tileCount;
+    h->tilesY = (height + p.tileH - 1) / p.tileH;
+    h->nTiles = m.tilesX * h->tilesY;
+    h->tilesPerOwner = (h->nTiles + p.tileCount - 1) / p.tileCount;
+    h->nTilesOwned = (h->nTiles - p.tileIndex + p.tileCount - 1) / p.tileCount;
+    if (h->nTilesOwned < 0)
+        h->nTilesOwned = 0;
+    m.slotsPerOwner = h->tilesPerOwner * p.tileW * p.tileH;
+    h->tileBytes = (size_t)m.slotsPerOwner * 16;
+    CREATE_TRY(hipMalloc(&h->tiles, h->tileBytes));
+    CREATE_TRY(hipMemsetAsync(h->tiles, 0, h->tileBytes, h->stream));
+    if (p.flags & KAJO_FLAG_COUNTERS) {
+        CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->counters), 4 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemsetAsync(h->counters, 0, 4 * sizeof(unsigned long long), h->stream));
+    }
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    *out = h;
+    return KAJO_OK;
+}
+
+int kajo_hip_destroy(kajo_hip_t h)
+{
+    destroy(h);
+    return KAJO_OK;
+}
+
+int kajo_hip_set_stream(kajo_hip_t h, void* stream)
+{
+    if (!h)
+        return fail(KAJO_E_INVALID, "null handle");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->ownStream)
+        HIP_TRY(hipStreamDestroy(h->stream));
+    h->stream = static_cast<hipStream_t>(stream);
+    h->ownStream = false;
+    return KAJO_OK;
+}
+
+int kajo_hip_render(kajo_hip_t h, int passes)
+{
+    if (!h)
+        return fail(KAJO_E_INVALID, "null handle");
+    if (passes < 0 || h->passesDone + (long long)passes > 65535)
+        return fail(KAJO_E_INVALID, "pass count out of range (stream key holds 16 bits)");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (passes == 0 || h->nTilesOwned == 0) {
+        h->passesDone += passes;
+        return KAJO_OK;
+    }
+    const KajoParams& p = h->params;
+    RenderArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.scene = h->view;
+    a.tiles = h->tiles;
+    a.W = h->W;
+    a.H = h->H;
+    a.n = (int)std::sqrt((double)(unsigned)p.samplesPerPass); // Renderer.cpp:38
+    a.S = (float)(unsigned)p.samplesPerPass;
+    a.pixelWidth = 1.f / h->W;   // Renderer.cpp:39-42
+    a.pixelHeight = 1.f / h->H;
+    a.sampleWidth = a.pixelWidth / a.n;
+    a.sampleHeight = a.pixelHeight / a.n;
+    a.depthLimit = p.depthLimit;
+    a.seed = p.seed;
+    a.tileW = p.tileW;
+    a.tileH = p.tileH;
+    a.tilesX = h->map.tilesX;
+    a.tilesY = h->tilesY;
+    a.tileIndex = p.tileIndex;
+    a.tileCount = p.tileCount;
+    a.nTilesOwned = h->nTilesOwned;
+    a.counters = h->counters;
+
+    const int wavesPerTile = (p.tileW / 8) * (p.tileH / 8);
+    const unsigned block = 256;
+    const unsigned grid = (unsigned)((long long)h->nTilesOwned * wavesPerTile / 4);
+    const int perLaunch = p.passesPerLaunch > 0 ? p.passesPerLaunch : 16;
+    int left = passes;
+    while (left > 0) {
+        const int now = left < perLaunch ? left : perLaunch;
+        a.firstPass = h->passesDone + 1;
+        a.nPasses = now;
+        hipEvent_t e0, e1;
+        if ((rc = getEvent(h, &e0)) || (rc = getEvent(h, &e1)))
+            return rc;
+        HIP_TRY(hipEventRecord(e0, h->stream));
+        hipError_t le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, grid, block, h->ldsBytes, h->stream)
+                                                 : kajo_render_fast_launch(&a, grid, block, h->ldsBytes, h->stream));
+        if (le != hipSuccess)
+            return failHip(le, "render kernel launch");
+        HIP_TRY(hipEventRecord(e1, h->stream));
+        h->pending.emplace_back(e0, e1);
+        h->launches++;
+        h->passesDone += now;
+        left -= now;
+    }
+    h->frameValid = false;
+    return KAJO_OK;
+}
+
+int kajo_hip_wait(kajo_hip_t h)
+{
+    if (!h)
+        return fail(KAJO_E_INVALID, "null handle");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return drainEvents(h);
+}
+
+int kajo_hip_reset(kajo_hip_t h)
+{
+    if (!h)
+        return fail(KAJO_E_INVALID, "null handle");
+    int rc = kajo_hip_wait(h);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemsetAsync(h->tiles, 0, h->tileBytes, h->stream));
+    if (h->counters)
+        HIP_TRY(hipMemsetAsync(h->counters, 0, 4 * sizeof(unsigned long long), h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    h->passesDone = 0;
+    h->frameValid = false;
+    h->kernelMs = 0.0;
+    h->launches = 0;
+    return KAJO_OK;
+}
+
+int kajo_hip_tile_buffer(kajo_hip_t h, void** devicePtr, size_t* bytes)
+{
+    if (!h || !devicePtr || !bytes)
+        return fail(KAJO_E_INVALID, "null argument");
+    *devicePtr = h->tiles;
+    *bytes = h->tileBytes;
+    return KAJO_OK;
+}
+
+int kajo_hip_compose(kajo_hip_t h, const void* gathered)
+{
+    if (!h || !gathered)
+        return fail(KAJO_E_INVALID, "null argument");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if ((rc = ensureFrame(h)))
+        return rc;
+    HIP_TRY((hipError_t)kajo_compose_launch(gathered, &h->map, h->frame, h->stream));
+    h->frameValid = true;
+    return KAJO_OK;
+}
+
+int kajo_hip_resolve_argb8_device(kajo_hip_t h, void* dst)
+{
+    if (!h || !dst)
+        return fail(KAJO_E_INVALID, "null argument");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (h->passesDone < 1)
+        return fail(KAJO_E_STATE, "nothing rendered yet");
+    if ((rc = composeOwn(h)))
+        return rc;
+    const int count = h->W * h->H;
+    hipError_t le = (hipError_t)(h->strict() ? kajo_resolve_strict_launch(h->frame, count, (float)h->passesDone, dst, h->stream)
+                                             : kajo_resolve_fast_launch(h->frame, count, (float)h->passesDone, dst, h->stream));
+    if (le != hipSuccess)
+        return failHip(le, "resolve kernel launch");
+    return KAJO_OK;
+}
+
+int kajo_hip_resolve_argb8(kajo_hip_t h, uint32_t* dst)
+{
+    if (!h || !dst)
+        return fail(KAJO_E_INVALID, "null argument");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    const size_t bytes = (size_t)h->W * h->H * 4;
+    if (!h->argb)
+        HIP_TRY(hipMalloc(&h->argb, bytes));
+    if ((rc = kajo_hip_resolve_argb8_device(h, h->argb)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(dst, h->argb, bytes, hipMemcpyDeviceToHost, h->stream));
+    return kajo_hip_wait(h);
+}
+
+int kajo_hip_read_radiance(kajo_hip_t h, float* dst)
+{
+    if (!h || !dst)
+        return fail(KAJO_E_INVALID, "null argument");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if ((rc = composeOwn(h)))
+        return rc;
+    HIP_TRY(hipMemcpyAsync(dst, h->frame, (size_t)h->W * h->H * 16, hipMemcpyDeviceToHost, h->stream));
+    return kajo_hip_wait(h);
+}
+
+int kajo_hip_counters(kajo_hip_t h, KajoCounters* out)
+{
+    if (!h || !out)
+        return fail(KAJO_E_INVALID, "null argument");
+    int rc = kajo_hip_wait(h);
+    if (rc)
+        return rc;
+    std::memset(out, 0, sizeof *out);
+    const int n = (int)std::sqrt((double)(unsigned)h->params.samplesPerPass);
+    // pixels this handle owns
+    unsigned long long pixels = 0;
+    for (int t = h->params.tileIndex; t < h->nTiles; t += h->params.tileCount) {
+        const int tx = t % h->map.tilesX, ty = t / h->map.tilesX;
+        const int w = std::min(h->map.tileW, h->W - tx * h->map.tileW);
+        const int hh = std::min(h->map.tileH, h->H - ty * h->map.tileH);
+        pixels += (unsigned long long)w * hh;
+    }
+    out->passes = (uint64_t)h->passesDone;
+    out->paths = pixels * (unsigned long long)(n * n) * (unsigned long long)h->passesDone;
+    out->kernelMs = h->kernelMs;
+    out->launches = h->launches;
+    if (h->counters) {
+        unsigned long long c[4];
+        HIP_TRY(hipMemcpy(c, h->counters, sizeof c, hipMemcpyDeviceToHost));
+        out->traversals = c[0];
+        out->vertices = c[1];
+        out->laneSlots = c[2];
+        out->primitiveTests = c[0] * (unsigned long long)(h->view.nPlanes + h->view.nSpheres);
+    }
+    return KAJO_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,705 @@
+// integrator.inc.hip -- the per-pixel Monte-Carlo integrator as ONE wave64 megakernel.
+//
+// Included twice: kernel_fast.hip (KAJO_STRICT 0, compiled with FMA contraction and the
+// gfx950 hardware transcendentals) and kernel_strict.hip (KAJO_STRICT 1, compiled
+// -ffp-contract=off, include/kajo_strictmath.h for the five libm functions, IEEE divide and
+// sqrt, binary64 exactly where the reference's expressions promote through M_PI / M_1_PI).
+// STRICT exists to prove that the kernel takes, path for path, the decisions of the CPU
+// integrator (it is compared bit for bit with the oracle); FAST is the product path.
+//
+// What it replaces (reference file:line):
+//   camera ray generation + sample loop     renderer/cpu/Renderer.cpp:38-72
+//   closest hit over planes, then spheres   renderer/cpu/Raytracer.cpp:21-138
+//   Russian roulette, lobe choice, MIS      renderer/cpu/Shader.cpp:50-215
+//   Lambert / Phong / mirror / refraction   renderer/cpu/BSDF.cpp:14-136
+//   spherical light sampling                renderer/cpu/Light.cpp:26-62
+//   the shuffle-add generator               renderer/cpu/Random.cpp:27-53,104-117
+//
+// Execution model (not the reference's): one lane owns one pixel of an 8x8 block and works
+// through that pixel's n*n*passes camera paths in the reference's order, so the per-pixel
+// float sums are formed exactly as Renderer.cpp:66-71 forms them. A path is a little state
+// machine; every trip round the loop traces exactly ONE ray per lane (camera/extension ray
+// or shadow ray) through the brute-force closest-hit loop -- the part that is 65 % of the
+// reference's CPU time -- with all 64 lanes testing the same primitive from one LDS
+// broadcast read. When a lane's path ends (Russian roulette kills 65 % at the first vertex)
+// the lane starts its next camera path in the same trip: lanes regenerate work locally
+// instead of idling until the longest path of the wave finishes. Shader::shade's recursion
+// is a loop carrying a throughput; calculateLightProbabilities' re-traces are replaced by
+// the hit of the extension ray that they duplicate (same ray, Shader.cpp:197-205).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "device_scene.h"
+#include "kajo_stream.h"
+#include "render_args.h"
+#if KAJO_STRICT
+#include "kajo_strictmath.h"
+#endif
+
+#define KDEV __device__ __forceinline__
+
+namespace
+{
+
+struct F3
+{
+    float x, y, z;
+};
+
+KDEV F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+KDEV F3 operator+(F3 a, F3 b) { return f3(a.x + b.x, a.y + b.y, a.z + b.z); }
+KDEV F3 operator-(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+KDEV F3 operator-(F3 a) { return f3(-a.x, -a.y, -a.z); }
+KDEV F3 operator*(F3 a, float s) { return f3(a.x * s, a.y * s, a.z * s); }
+KDEV F3 operator*(float s, F3 a) { return f3(a.x * s, a.y * s, a.z * s); }
+KDEV F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
+KDEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+KDEV F3 cross(F3 a, F3 b) { return f3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
+KDEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
+
+// ---- numerics policy ------------------------------------------------------------------
+#if KAJO_STRICT
+KDEV float kdiv(float a, float b) { return a / b; }
+KDEV float ksqrt(float a) { return __builtin_sqrtf(a); }
+KDEV float krcp(float a) { return 1.0f / a; }
+KDEV float kpow(float x, float y) { return kajo_powf(x, y); }
+#else
+KDEV float kdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+KDEV float ksqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+KDEV float krcp(float a) { return __builtin_amdgcn_rcpf(a); }
+// x >= 0 (clamped cosine / uniform variate / clamped colour): x^y = 2^(y log2 x); v_log(0) = -inf
+// gives 2^-inf = 0 for y > 0, and y == 0 is answered explicitly as libm does (pow(x, 0) = 1)
+KDEV float kpow(float x, float y)
+{
+    float r = __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x));
+    return y == 0.0f ? 1.0f : r;
+}
+#endif
+
+KDEV F3 normalize(F3 a)
+{
+    float sqr = a.x * a.x + a.y * a.y + a.z * a.z;
+#if KAJO_STRICT
+    return a * (1.0f / __builtin_sqrtf(sqr)); // glm: x * inversesqrt(dot), inversesqrt = 1 / sqrt
+#else
+    return a * __builtin_amdgcn_rsqf(sqr);
+#endif
+}
+
+KDEV float length(F3 a) { return ksqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+KDEV F3 reflect(F3 I, F3 N) { return I - N * dot(N, I) * 2.0f; }
+
+const float kEps = 0.001f;              // g_surfaceEpsilon, Shader.cpp:23
+const float kFltEpsilon = 1.1920929e-7f; // std::numeric_limits<float>::epsilon()
+#if KAJO_STRICT
+const double kPi = 3.14159265358979323846;
+const double kInvPi = 0.31830988618379067154;
+#else
+const float kInvPiF = 0.31830988618379067154f;
+const float kInv2PiF = 0.15915494309189533577f;
+#endif
+
+// ---- RNG (Random.cpp:27-53): state = (lo, hi); hi += perm(hi), lo += old hi -----------
+struct Rng
+{
+    uint64_t lo, hi;
+};
+
+KDEV void rngStep(Rng& r)
+{
+    uint64_t h = r.hi;
+    uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+    // 16-bit words [a,b,c,d] -> [c,d,b,a]: low dword = old high dword, high dword = rot16(old low)
+    uint64_t p = (uint64_t)h1 | ((uint64_t)__builtin_amdgcn_alignbit(h0, h0, 16) << 32);
+    r.lo = r.lo + h;
+    r.hi = h + p;
+}
+
+KDEV float lane32(uint32_t bits) { return __fmul_rn((float)(int32_t)bits, 4.6566128730773926e-10f); } // * 2^-31
+
+// uniform in [0,1): x * .5 + .5 with one rounding per operation in BOTH modes, so that a coin
+// never flips merely because FAST contracted the expression (Random.cpp:113)
+KDEV float unit(float g) { return __fadd_rn(__fmul_rn(g, .5f), .5f); }
+
+// flipCoin, Random.cpp:111-117
+KDEV bool flipCoin(Rng& r, float probability, float& outProbability)
+{
+    rngStep(r);
+    float u = unit(lane32((uint32_t)r.lo));
+    bool v = (probability != 0.0f) && (u <= probability);
+    outProbability = v ? probability : __fsub_rn(1.0f, probability);
+    return v;
+}
+
+// ---- closest hit (Raytracer.cpp:21-138) --------------------------------------------------
+struct Hit
+{
+    int id;     // 0 miss; 1..nPlanes planes; nPlanes+1.. spheres
+    float t;    // ray.maxDistance after the walk
+    float t0;   // object-space parameter of a sphere hit
+};
+
+struct LdsScene
+{
+    const DFloat4* planeRow;
+    const float* planeDet;
+    const DFloat4* sphereHot;
+    const uint32_t* sphereHotOffset;
+};
+
+KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
+{
+    float tMax = __builtin_inff(); // Ray.cpp:10-13; minDistance = 0
+    int best = 0;
+    float bestT0 = 0.0f;
+
+    const int np = sc.nPlanes;
+    for (int i = 0; i < np; i++) { // Raytracer.cpp:74-98; only row y of the inverse matters
+        const DFloat4 r = lds.planeRow[i];
+        const float det = lds.planeDet[i];
+        float denom = r.x * d.x + r.y * d.y + r.z * d.z;
+        float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w * 1.0f;
+        float t = kdiv(-oy, denom);
+        float ts = t * det;
+        bool ok = !(__builtin_fabsf(denom) < kFltEpsilon) && !(t < 0.0f) && !(ts > tMax || ts < 0.0f);
+        tMax = ok ? ts : tMax;
+        best = ok ? i + 1 : best;
+    }
+
+    const int ns = sc.nSpheres;
+    const float aT = dot(d, d); // a of every translated sphere (mat3(inverse) = identity)
+    for (int i = 0; i < ns; i++) { // Raytracer.cpp:21-72
+        float a, b, c, det;
+        if (sc.allTranslated || !(lds.sphereHotOffset[i] & KAJO_SPHERE_GENERAL)) {
+            const DFloat4 s = lds.sphereHot[sc.allTranslated ? i : (int)lds.sphereHotOffset[i]];
+            F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+            a = aT;
+            b = 2 * dot(d, o);
+            c = dot(o, o) - s.w;
+            det = 1.0f;
+        } else {
+            const int k = (int)(lds.sphereHotOffset[i] & ~KAJO_SPHERE_GENERAL);
+            const DFloat4 r0 = lds.sphereHot[k], r1 = lds.sphereHot[k + 1], r2 = lds.sphereHot[k + 2];
+            const DFloat4 q = lds.sphereHot[k + 3];
+            F3 dir = f3(r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z,
+                        r2.x * d.x + r2.y * d.y + r2.z * d.z);
+            F3 o = f3(r0.x * O.x + r0.y * O.y + r0.z * O.z + r0.w * 1.0f, r1.x * O.x + r1.y * O.y + r1.z * O.z + r1.w * 1.0f,
+                      r2.x * O.x + r2.y * O.y + r2.z * O.z + r2.w * 1.0f);
+            a = dot(dir, dir);
+            b = 2 * dot(dir, o);
+            c = dot(o, o) - q.x;
+            det = q.y;
+        }
+        float discr = b * b - 4 * a * c;
+        float sq = ksqrt(discr);
+        float q = (b < 0.0f) ? (-b - sq) * .5f : (-b + sq) * .5f;
+        float t0 = kdiv(q, a);
+        float t1 = kdiv(c, q);
+        bool sw = t0 > t1;
+        float lo = sw ? t1 : t0, hi = sw ? t0 : t1;
+        float th = (lo < 0.0f) ? hi : lo;
+        float ts = th * det;
+        bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(ts > tMax || ts < 0.0f);
+        tMax = ok ? ts : tMax;
+        best = ok ? np + 1 + i : best;
+        bestT0 = ok ? th : bestT0;
+    }
+    return Hit{best, tMax, bestT0};
+}
+
+// ---- surface point of an accepted hit ------------------------------------------------------
+struct Surface
+{
+    F3 P, N; // position, shading normal
+};
+
+KDEV void sphereFrame(F3 n, F3& tg, F3& bn) // Raytracer.cpp:55-65
+{
+    float smallest = fminf(n.z, fminf(n.x, n.y));
+    F3 t;
+    if (n.x == smallest)
+        t = f3(0.0f, -n.z, n.y);
+    else if (n.y == smallest)
+        t = f3(-n.z, 0.0f, n.x);
+    else
+        t = f3(-n.y, n.x, 0.0f);
+    tg = normalize(t);
+    bn = cross(n, tg);
+}
+
+KDEV F3 hitNormal(const DSceneView& sc, const LdsScene& lds, const Hit& h, F3 O, F3 d)
+{
+    if (h.id <= sc.nPlanes) {
+        const DFloat4 n = sc.planeFrame[3 * (h.id - 1)];
+        return f3(n.x, n.y, n.z);
+    }
+    const int si = h.id - 1 - sc.nPlanes;
+    const uint32_t off = sc.allTranslated ? (uint32_t)si : lds.sphereHotOffset[si];
+    if (!(off & KAJO_SPHERE_GENERAL)) {
+        const DFloat4 s = lds.sphereHot[off];
+        F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+        return normalize(o + d * h.t0); // mat3(M) = identity
+    }
+    const int k = (int)(off & ~KAJO_SPHERE_GENERAL);
+    const DFloat4 r0 = lds.sphereHot[k], r1 = lds.sphereHot[k + 1], r2 = lds.sphereHot[k + 2];
+    F3 dir = f3(r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z,
+                r2.x * d.x + r2.y * d.y + r2.z * d.z);
+    F3 o = f3(r0.x * O.x + r0.y * O.y + r0.z * O.z + r0.w * 1.0f, r1.x * O.x + r1.y * O.y + r1.z * O.z + r1.w * 1.0f,
+              r2.x * O.x + r2.y * O.y + r2.z * O.z + r2.w * 1.0f);
+    F3 n = o + dir * h.t0;
+    const float* m = sc.sphereCold[si].m;
+    return normalize(f3(m[0] * n.x + m[1] * n.y + m[2] * n.z, m[3] * n.x + m[4] * n.y + m[5] * n.z,
+                        m[6] * n.x + m[7] * n.y + m[8] * n.z));
+}
+
+// ---- BSDFs (BSDF.cpp). kind: 0 Lambert, 1 Phong, 2 ideal reflector ----------------------------
+KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
+{
+    if (kind == 0) { // BSDF.cpp:30-33
+#if KAJO_STRICT
+        return color * (float)kInvPi;
+#else
+        return color * kInvPiF;
+#endif
+    }
+    if (kind == 1) { // BSDF.cpp:62-67
+        float cosA = fmaxf(0.0f, dot(R, dir));
+#if KAJO_STRICT
+        float s = (float)((double)(exponent + 1) / (2 * kPi));
+#else
+        float s = (exponent + 1) * kInv2PiF;
+#endif
+        return (s * color) * kpow(cosA, exponent);
+    }
+    float cosA = fmaxf(0.0f, dot(dir, N)); // BSDF.cpp:87-91
+    return f3(kdiv(color.x, cosA), kdiv(color.y, cosA), kdiv(color.z, cosA));
+}
+
+KDEV float bsdfProbability(int kind, float exponent, F3 R, F3 N, F3 dir)
+{
+    if (kind == 0) { // BSDF.cpp:35-39
+        float cosT = dot(dir, N);
+#if KAJO_STRICT
+        return (float)(kInvPi * (double)cosT);
+#else
+        return kInvPiF * cosT;
+#endif
+    }
+    if (kind == 1) { // BSDF.cpp:69-74
+        float cosA = fmaxf(0.0f, dot(R, dir));
+#if KAJO_STRICT
+        return (float)((double)(exponent + 1) / (2 * kPi) * (double)kpow(cosA, exponent));
+#else
+        return (exponent + 1) * kInv2PiF * kpow(cosA, exponent);
+#endif
+    }
+    return 0.0f; // BSDF.cpp:93-96
+}
+
+// generateSample of Lambert / Phong / reflector (BSDF.cpp:20-28,48-60,82-85 with
+// Random.cpp:77-102). tg/bn only read for Lambert.
+KDEV F3 bsdfGenerate(int kind, float exponent, F3 R, F3 N, F3 tg, F3 bn, Rng& rng, float& pdf)
+{
+    if (kind == 2) {
+        pdf = 1.0f;
+        return R;
+    }
+    rngStep(rng);
+    float u = unit(lane32((uint32_t)rng.lo));         // .5f * x + .5f
+    float v = unit(lane32((uint32_t)(rng.lo >> 32)));
+    if (kind == 0) {
+        float r = ksqrt(u);
+#if KAJO_STRICT
+        float phi = (float)((double)(v * 2) * kPi);
+        float x = r * kajo_cosf(phi);
+        float y = r * kajo_sinf(phi);
+        float z = __builtin_sqrtf(fmaxf(0.0f, 1.0f - u));
+        pdf = (float)((double)z * kInvPi);
+#else
+        float x = r * __builtin_amdgcn_cosf(v); // v_cos_f32 takes revolutions: cos(2 pi v)
+        float y = r * __builtin_amdgcn_sinf(v);
+        float z = ksqrt(fmaxf(0.0f, 1.0f - u));
+        pdf = z * kInvPiF;
+#endif
+        return tg * x + bn * y + N * z;
+    }
+    F3 s;
+#if KAJO_STRICT
+    float a = kajo_acosf(kajo_powf(u, 1.0f / (exponent + 1)));
+    float phi = (float)(2 * kPi * (double)v);
+    s = f3(kajo_sinf(a) * kajo_cosf(phi), kajo_sinf(a) * kajo_sinf(phi), kajo_cosf(a));
+    pdf = (float)((double)(exponent + 1) / (2 * kPi) * (double)kajo_powf(kajo_cosf(a), exponent));
+#else
+    // cos(acos(c)) = c and sin(acos(c)) = sqrt(1 - c^2): no inverse trigonometry needed
+    float lg = __builtin_amdgcn_logf(u);
+    float ca = __builtin_amdgcn_exp2f(lg * krcp(exponent + 1));
+    float sa = ksqrt(fmaxf(0.0f, 1.0f - ca * ca));
+    s = f3(sa * __builtin_amdgcn_cosf(v), sa * __builtin_amdgcn_sinf(v), ca);
+    pdf = (exponent + 1) * kInv2PiF * kpow(ca, exponent);
+#endif
+    F3 uu = normalize(cross(f3(0.0f, 0.0f, 1.0f), R));
+    F3 vv = cross(uu, R);
+    return f3(uu.x * s.x + vv.x * s.y + R.x * s.z, uu.y * s.x + vv.y * s.y + R.y * s.z,
+              uu.z * s.x + vv.z * s.y + R.z * s.z);
+}
+
+// IdealTransmissionBSDF::generateSample, BSDF.cpp:105-124 + glm::refract
+KDEV F3 transmissionDirection(F3 view, F3 N, float ior)
+{
+    float cosA = dot(view, N);
+    bool entering = cosA < 0.0f;
+    F3 n = entering ? N : -N;
+    float eta = entering ? kdiv(1.0f, ior) : kdiv(ior, 1.0f);
+    cosA = dot(view, n);
+    float k = 1.0f - eta * eta * (1.0f - cosA * cosA);
+    if (k < 0.0f)
+        return reflect(view, n);
+    float dv = dot(n, view);
+    return eta * view - (eta * dv + ksqrt(k)) * n;
+}
+
+// ---- SphericalLight (Light.cpp:26-62) -------------------------------------------------------
+KDEV float solidAngle(F3 centre, float radius, F3 P)
+{
+    float dist = length(centre - P);
+#if KAJO_STRICT
+    if (dist < radius)
+        return (float)(4 * kPi);
+    return (float)(2 * kPi * (double)(1 - kajo_cosf(kajo_asinf(radius / dist))));
+#else
+    // 1 - cos(asin x) = x^2 / (1 + sqrt(1 - x^2)): same value without the cancellation
+    float x = radius * krcp(dist);
+    float x2 = x * x;
+    float v = 6.28318530717958647692f * x2 * krcp(1.0f + ksqrt(fmaxf(0.0f, 1.0f - x2)));
+    return dist < radius ? 12.56637061435917295385f : v;
+#endif
+}
+
+KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
+{
+    rngStep(rng);
+    float g0 = lane32((uint32_t)rng.lo), g1 = lane32((uint32_t)(rng.lo >> 32)), g2 = lane32((uint32_t)rng.hi);
+    float s1 = unit(g0), s2 = unit(g1), s3 = unit(g2);
+#if KAJO_STRICT
+    float ang = (float)(2 * kPi * (double)s2);
+    float x = radius * __builtin_sqrtf(s1) * kajo_cosf(ang);
+    float y = radius * __builtin_sqrtf(s1) * kajo_sinf(ang);
+    float z = __builtin_sqrtf(radius * radius - x * x - y * y) * kajo_sinf((float)(kPi * (double)(s3 - .5f)));
+#else
+    float rs = radius * ksqrt(s1);
+    float x = rs * __builtin_amdgcn_cosf(s2);
+    float y = rs * __builtin_amdgcn_sinf(s2);
+    float z = ksqrt(radius * radius - x * x - y * y) * __builtin_amdgcn_sinf((s3 - .5f) * .5f);
+#endif
+    F3 dir = normalize(centre + f3(x, y, z) - P);
+    pdf = krcp(solidAngle(centre, radius, P));
+    return dir;
+}
+
+// ---- path state ---------------------------------------------------------------------------
+enum : int
+{
+    MODE_NEW = 0,    // fetch the next camera path of this lane's pixel
+    MODE_EXTEND = 1, // the traced ray continues the path: shade what it hit
+    MODE_SHADOW = 2, // the traced ray asks whether light `lightK` is visible
+    MODE_DONE = 3
+};
+
+} // namespace
+
+extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    const DSceneView& sc = args.scene;
+
+    // ---- stage the hot scene records into LDS (one copy per workgroup) --------------------
+    DFloat4* ldsPlaneRow = reinterpret_cast<DFloat4*>(ldsRaw);
+    DFloat4* ldsSphereHot = ldsPlaneRow + sc.nPlanes;
+    float* ldsPlaneDet = reinterpret_cast<float*>(ldsSphereHot + sc.nSphereHot);
+    uint32_t* ldsSphereOff = reinterpret_cast<uint32_t*>(ldsPlaneDet + sc.nPlanes);
+    for (int i = threadIdx.x; i < sc.nPlanes; i += blockDim.x) {
+        ldsPlaneRow[i] = sc.planeRow[i];
+        ldsPlaneDet[i] = sc.planeDet[i];
+    }
+    for (int i = threadIdx.x; i < sc.nSphereHot; i += blockDim.x)
+        ldsSphereHot[i] = sc.sphereHot[i];
+    for (int i = threadIdx.x; i < sc.nSpheres; i += blockDim.x)
+        ldsSphereOff[i] = sc.sphereHotOffset[i];
+    __syncthreads();
+    const LdsScene lds{ldsPlaneRow, ldsPlaneDet, ldsSphereHot, ldsSphereOff};
+
+    // ---- which pixel is mine ----------------------------------------------------------------
+    const int lane = threadIdx.x & 63;
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; // index into the tile buffer
+    const int wave = (int)(slot >> 6);
+    const int wavesPerTile = (args.tileW >> 3) * (args.tileH >> 3);
+    const int ownedTile = wave / wavesPerTile;
+    const int wb = wave - ownedTile * wavesPerTile;
+    const int tile = args.tileIndex + ownedTile * args.tileCount;
+    const int tx = tile % args.tilesX, ty = tile / args.tilesX;
+    const int bxi = wb % (args.tileW >> 3), byi = wb / (args.tileW >> 3);
+    const int px = tx * args.tileW + bxi * 8 + (lane & 7);
+    const int py = ty * args.tileH + byi * 8 + (lane >> 3);
+    const bool inImage = ownedTile < args.nTilesOwned && px < args.W && py < args.H;
+
+    const int n = args.n;
+    const int nn = n * n;
+    const uint32_t pixelIndex = (uint32_t)(py * args.W + px);
+    const uint64_t seedKey = args.seed * 0x9E3779B97F4A7C15ull;
+
+    const F3 p1 = ld3(sc.p1), dp2 = ld3(sc.dp2), dp3 = ld3(sc.dp3), origin = ld3(sc.origin);
+    const F3 background = ld3(sc.background);
+    const int np = sc.nPlanes;
+
+    // accumulated radiance of the pixel (Renderer.cpp:70-71), continued across launches
+    // (the handle zeroes the buffer when it is created or reset)
+    F3 total = f3(0.0f, 0.0f, 0.0f);
+    float totalW = 0.0f;
+    if (inImage) {
+        const float4 t = reinterpret_cast<const float4*>(args.tiles)[slot];
+        total = f3(t.x, t.y, t.z);
+        totalW = t.w;
+    }
+
+    // ---- per-lane path state ----------------------------------------------------------------
+    int mode = inImage ? MODE_NEW : MODE_DONE;
+    int pass = args.firstPass;
+    int sample = 0;
+    F3 radiance = f3(0.0f, 0.0f, 0.0f); // sum over the pixel's samples of this pass
+    Rng rng{0, 0};
+    F3 O = origin, d = f3(0.0f, 0.0f, 1.0f);
+    F3 L = f3(0.0f, 0.0f, 0.0f), T = f3(1.0f, 1.0f, 1.0f);
+    int depth = 0;
+    bool collectEmission = true;
+    // vertex being shaded
+    F3 vP = origin, vN = d, vR = d, vE = L, vLd = L, vColor = L;
+    int vId = 0, vKind = 0, lightK = 0;
+    float vExp = 0.0f, vS = 0.0f;
+    F3 pendContrib = L; // light sample's contribution if its shadow ray reaches the light
+    // extension ray sampled from the BSDF: weight pieces that wait for the light pdf of the hit
+    bool pendBsdf = false;
+    F3 pendF = L;
+    float pendCos = 0.0f, pendP = 0.0f;
+
+    unsigned long long ctrTraversals = 0, ctrVertices = 0, ctrSlots = 0;
+    const bool counting = args.counters != nullptr;
+
+    for (;;) {
+        // ---- MODE_NEW: camera ray of the next sample (Renderer.cpp:55-64) ---------------------
+        if (mode == MODE_NEW) {
+            if (sample == nn) { // pass complete: Renderer.cpp:70-71
+                total = total + f3(kdiv(radiance.x, args.S), kdiv(radiance.y, args.S), kdiv(radiance.z, args.S));
+                radiance = f3(0.0f, 0.0f, 0.0f);
+                sample = 0;
+                pass++;
+            }
+            if (pass >= args.firstPass + args.nPasses) {
+                mode = MODE_DONE;
+            } else {
+                const int sampleY = sample / n, sampleX = sample - sampleY * n;
+                uint64_t z = seedKey ^ ((uint64_t)(uint32_t)pass << 48) ^ ((uint64_t)(uint32_t)sample << 32) ^
+                             (uint64_t)pixelIndex;
+                rng.lo = kajo_splitmix64(&z);
+                rng.hi = kajo_splitmix64(&z);
+                rngStep(rng);
+                float offX = unit(lane32((uint32_t)rng.lo));
+                float offY = unit(lane32((uint32_t)(rng.lo >> 32)));
+                float sx = px * args.pixelWidth + sampleX * args.sampleWidth + offX * args.sampleWidth;
+                float sy = (args.H - py) * args.pixelHeight + sampleY * args.sampleHeight + offY * args.sampleHeight;
+                F3 dir = p1 + dp2 * sx + dp3 * sy - origin;
+                d = normalize(dir);
+                O = origin;
+                L = f3(0.0f, 0.0f, 0.0f);
+                T = f3(1.0f, 1.0f, 1.0f);
+                depth = 0;
+                collectEmission = true;
+                pendBsdf = false;
+                sample++;
+                mode = MODE_EXTEND;
+            }
+        }
+        const bool active = mode != MODE_DONE;
+        const unsigned long long activeMask = __ballot(active);
+        if (activeMask == 0ull)
+            break;
+
+        // ---- one ray per lane through the whole scene ------------------------------------------
+        const Hit hit = trace(sc, lds, O, d);
+        if (counting) {
+            ctrTraversals += __builtin_popcountll(activeMask);
+            ctrSlots += 64;
+        }
+
+        bool sampleNext = false; // continue with the light loop / BSDF sampling of vertex v*
+        bool pathDone = false;
+
+        if (mode == MODE_EXTEND) {
+            // weight of the BSDF-sampled segment that just ended (Shader.cpp:203-212)
+            if (pendBsdf) {
+                float pL = 0.0f;
+                if (hit.id > np && hit.id != vId) {
+                    const int si = hit.id - 1 - np;
+                    if (sc.material[hit.id - 1].isLight) {
+                        const DSphereCold& lc = sc.sphereCold[si];
+                        pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));
+                    }
+                }
+                F3 wb = (krcp(pL + pendP) * pendF) * pendCos;
+                T = T * (vS * wb);
+                collectEmission = false; // SampleNonEmissiveObjects
+                pendBsdf = false;
+            }
+            if (hit.id == 0) { // Shader.cpp:116-117
+                L = L + T * background;
+                pathDone = true;
+            } else {
+                if (counting)
+                    ctrVertices += 1;
+                const DMaterial& m = sc.material[hit.id - 1];
+                const F3 view = d;
+                vP = O + d * hit.t; // Raytracer.cpp:134-135
+                vN = hitNormal(sc, lds, hit, O, d);
+                vId = hit.id;
+                vE = collectEmission ? ld3(m.emission) : f3(0.0f, 0.0f, 0.0f); // Shader.cpp:121
+                float pc;
+                const bool cont = flipCoin(rng, m.pRR, pc); // Shader.cpp:124-125
+                if (!cont || depth >= args.depthLimit) {
+                    L = L + T * (krcp(pc) * vE); // Shader.cpp:126-127
+                    pathDone = true;
+                } else {
+                    float pt;
+                    const bool transparent = flipCoin(rng, m.pT, pt); // Shader.cpp:130-134
+                    if (transparent) { // Shader.cpp:137-151; the BSDF colour is the SPECULAR colour
+                        F3 nd = transmissionDirection(view, vN, m.ior);
+                        float cosA = __builtin_fabsf(dot(nd, vN));
+                        F3 spec = ld3(m.specular);
+                        F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
+                        F3 w = (kdiv(krcp(pc) * 1.0f, pt) * f) * __builtin_fabsf(dot(vN, nd));
+                        L = L + T * (w * vE);
+                        T = T * w;
+                        O = vP + nd * kEps;
+                        d = nd;
+                        depth++;
+                        // mode stays MODE_EXTEND, the light sampling scheme is inherited
+                    } else {
+                        float pd;
+                        const bool diffuse = flipCoin(rng, m.pD, pd); // Shader.cpp:153-154
+                        vKind = diffuse ? 0 : (m.exponent != 0.0f ? 1 : 2);
+                        vColor = diffuse ? ld3(m.diffuse) : ld3(m.specular);
+                        vExp = m.exponent;
+                        vS = kdiv(kdiv(krcp(pc) * 1.0f, pt) * 1.0f, pd); // 1/pc * 1/pt * 1/pd
+                        vR = reflect(view, vN);
+                        vLd = f3(0.0f, 0.0f, 0.0f);
+                        lightK = 0;
+                        sampleNext = true;
+                    }
+                }
+            }
+        } else if (mode == MODE_SHADOW) {
+            // Shader.cpp:72-73: the sample counts iff the closest hit of the shadow ray IS the light
+            if (hit.id == np + 1 + sc.light[lightK])
+                vLd = vLd + pendContrib;
+            lightK++;
+            sampleNext = true;
+        }
+
+        if (sampleNext) {
+            // ---- sampleLights (Shader.cpp:50-86), one light per trip ------------------------------
+            bool shadowRay = false;
+            while (lightK < sc.nLights) {
+                const int si = sc.light[lightK];
+                if (np + 1 + si == vId) { // a light does not sample itself
+                    lightK++;
+                    continue;
+                }
+                const DSphereCold& lc = sc.sphereCold[si];
+                float pl;
+                const F3 l = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
+                // The reference traces first and asks the BSDF afterwards; a zero BSDF pdf (always for
+                // the reflector, outside the lobe for Phong) discards the sample either way, so the
+                // trace is skipped for it.
+                const float pb = bsdfProbability(vKind, vExp, vR, vN, l);
+                if (pl == 0.0f || pb == 0.0f) {
+                    lightK++;
+                    continue;
+                }
+                const F3 Le = ld3(sc.material[np + si].emission);
+                pendContrib = ((krcp(pb + pl) * bsdfEvaluate(vKind, vColor, vExp, vR, vN, l)) * fmaxf(0.0f, dot(vN, l))) * Le;
+                O = vP + l * kEps;
+                d = l;
+                mode = MODE_SHADOW;
+                shadowRay = true;
+                break;
+            }
+            if (!shadowRay) {
+                // ---- BSDF sampling (Shader.cpp:191-200) ------------------------------------------
+                F3 tg = f3(0.0f, 0.0f, 0.0f), bn = tg;
+                if (vKind == 0) {
+                    if (vId <= np) {
+                        const DFloat4 t4 = sc.planeFrame[3 * (vId - 1) + 1], b4 = sc.planeFrame[3 * (vId - 1) + 2];
+                        tg = f3(t4.x, t4.y, t4.z);
+                        bn = f3(b4.x, b4.y, b4.z);
+                    } else {
+                        sphereFrame(vN, tg, bn);
+                    }
+                }
+                float p;
+                const F3 nd = bsdfGenerate(vKind, vExp, vR, vN, tg, bn, rng, p);
+                L = L + T * (vS * (vE + vLd));
+                if (p == 0.0f) {
+                    pathDone = true;
+                } else {
+                    pendF = bsdfEvaluate(vKind, vColor, vExp, vR, vN, nd);
+                    pendCos = fmaxf(0.0f, dot(vN, nd));
+                    pendP = p;
+                    pendBsdf = true;
+                    O = vP + nd * kEps;
+                    d = nd;
+                    depth++;
+                    mode = MODE_EXTEND;
+                }
+            }
+        }
+
+        if (pathDone) {
+            radiance = radiance + L; // Renderer.cpp:66
+            mode = MODE_NEW;
+        }
+    }
+
+    if (inImage)
+        reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
+
+    if (counting && lane == 0) {
+        atomicAdd(&args.counters[0], ctrTraversals);
+        atomicAdd(&args.counters[2], ctrSlots);
+    }
+    if (counting) {
+        // vertices are per lane: reduce over the wave first
+        unsigned long long v = ctrVertices;
+        for (int o = 32; o > 0; o >>= 1)
+            v += __shfl_down(v, o);
+        if (lane == 0)
+            atomicAdd(&args.counters[1], v);
+    }
+}
+
+// ---- resolve (Renderer.cpp:73-75 + Image::linearToSRGB / colorToRGBA8, Image.cpp:14-27) ----------
+// frame: W*H float4 sums over passes; dst: ARGB8, row 0 = top.
+extern "C" __global__ void __launch_bounds__(256) KAJO_RESOLVE_NAME(const float4* frame, int count, float passes, uint32_t* dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count)
+        return;
+    const float4 a = frame[i];
+    const float in[3] = {a.x, a.y, a.z};
+    int out[3];
+    for (int k = 0; k < 3; k++) {
+        float v = kdiv(in[k], passes);
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        v = kpow(v, 1 / 2.2f);
+        out[k] = (int)(v * 255.f + .5f);
+    }
+    const int al = (int)(1.f * 255.f + .5f);
+    dst[i] = ((uint32_t)al << 24) | ((uint32_t)out[0] << 16) | ((uint32_t)out[1] << 8) | (uint32_t)out[2];
+}

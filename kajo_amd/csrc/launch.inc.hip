@@ -1,0 +1,25 @@
+// launch.inc.hip -- host-side launcher of the kernel defined by the including file.
+#define KAJO_CAT2(a, b) a##b
+#define KAJO_CAT(a, b) KAJO_CAT2(a, b)
+
+extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _launch)(const RenderArgs* args, unsigned grid, unsigned block, size_t ldsBytes,
+                                                void* stream)
+{
+    hipLaunchKernelGGL(KAJO_KERNEL_NAME, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
+    return (int)hipGetLastError();
+}
+
+// dynamic LDS above the 64 KiB default needs an explicit opt-in on the function
+extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(size_t ldsBytes)
+{
+    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+}
+
+extern "C" int KAJO_CAT(KAJO_RESOLVE_NAME, _launch)(const void* frame, int count, float passes, void* dst, void* stream)
+{
+    const unsigned block = 256, grid = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(KAJO_RESOLVE_NAME, dim3(grid), dim3(block), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float4*>(frame), count, passes, static_cast<uint32_t*>(dst));
+    return (int)hipGetLastError();
+}

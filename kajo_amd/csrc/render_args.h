@@ -1,0 +1,49 @@
+// render_args.h -- by-value argument block of the render / compose / resolve kernels.
+#ifndef KAJO_RENDER_ARGS_H
+#define KAJO_RENDER_ARGS_H
+
+#include <stdint.h>
+
+#include "device_scene.h"
+
+struct RenderArgs
+{
+    DSceneView scene;
+    void* tiles;          // this handle's compact tile buffer, float4 per slot
+    int32_t W, H;         // whole image
+    int32_t n;            // strata per axis = (int)sqrt(S), Renderer.cpp:38
+    float S;              // (float)S, the divisor of Renderer.cpp:71
+    float pixelWidth, pixelHeight, sampleWidth, sampleHeight; // Renderer.cpp:39-42
+    int32_t firstPass, nPasses;  // passes [firstPass, firstPass + nPasses), 1-based
+    int32_t depthLimit;
+    uint64_t seed;
+    int32_t tileW, tileH, tilesX, tilesY;
+    int32_t tileIndex, tileCount, nTilesOwned;
+    unsigned long long* counters; // [0] traversals, [1] vertices, [2] lane slots; may be null
+};
+
+// tile-buffer slot of pixel (x, y): tiles are dealt round-robin to `tileCount` owners; inside a
+// tile pixels are grouped in 8x8 blocks (one wave each) so that a wave's 64 float4 are
+// contiguous (1 KiB per store instruction).
+struct TileMap
+{
+    int32_t W, H, tileW, tileH, tilesX, tileCount;
+    int32_t slotsPerOwner; // padded tile count per owner * tileW * tileH
+};
+
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline void kajoTileSlot(const TileMap& m, int x, int y, int* owner, uint32_t* slot)
+{
+    const int tx = x / m.tileW, ty = y / m.tileH;
+    const int tile = ty * m.tilesX + tx;
+    const int ix = x - tx * m.tileW, iy = y - ty * m.tileH;
+    const int wavesPerTile = (m.tileW >> 3) * (m.tileH >> 3);
+    const int wb = (iy >> 3) * (m.tileW >> 3) + (ix >> 3);
+    const int lane = ((iy & 7) << 3) | (ix & 7);
+    *owner = tile % m.tileCount;
+    *slot = (uint32_t)(((tile / m.tileCount) * wavesPerTile + wb) * 64 + lane);
+}
+
+#endif

@@ -1,0 +1,115 @@
+"""Host-side driver of the HIP backend: the Python counterpart of hip::Scheduler
+(kajo_amd/host/HipScheduler.cpp), which in turn stands where cpu::Scheduler stands in the
+reference (renderer/cpu/Scheduler.cpp:53-85: own a renderer, run passes, hand pixels to the
+Image). Used by the tests, bench.py and the multi-GPU path; all rendering happens in
+libkajo_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .scene import Scene
+
+
+class HipRenderer:
+    def __init__(self, scene: Scene, width: int, height: int, spp: int = 32, depth_limit: int = 8,
+                 seed: int = 0o715517, strict: bool = False, counters: bool = False, device: int = 0,
+                 tile=(64, 16), tile_index: int = 0, tile_count: int = 1, passes_per_launch: int = 0):
+        L = capi.lib()
+        self._L = L
+        self.scene = scene
+        self.width, self.height = int(width), int(height)
+        self.n = int(np.sqrt(float(spp)))  # Renderer.cpp:38
+        p = capi.KajoParams()
+        L.kajo_hip_default_params(C.byref(p))
+        p.samplesPerPass = spp
+        p.depthLimit = depth_limit
+        p.seed = seed
+        p.flags = (capi.KAJO_FLAG_STRICT if strict else 0) | (capi.KAJO_FLAG_COUNTERS if counters else 0)
+        p.device = device
+        p.tileW, p.tileH = tile
+        p.tileIndex, p.tileCount = tile_index, tile_count
+        p.passesPerLaunch = passes_per_launch
+        self.params = p
+        self._pod = scene.pod()
+        h = C.c_void_p()
+        capi.check(L.kajo_hip_create(C.byref(self._pod), self.width, self.height, C.byref(p), C.byref(h)))
+        self._h = h
+        self.passes = 0
+
+    # -- lifecycle -------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.kajo_hip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- rendering -------------------------------------------------------------------------
+    def render(self, passes: int = 1, wait: bool = False):
+        capi.check(self._L.kajo_hip_render(self._h, int(passes)))
+        self.passes += int(passes)
+        if wait:
+            self.wait()
+        return self
+
+    def wait(self):
+        capi.check(self._L.kajo_hip_wait(self._h))
+
+    def reset(self):
+        capi.check(self._L.kajo_hip_reset(self._h))
+        self.passes = 0
+
+    def set_stream(self, stream_ptr: int):
+        capi.check(self._L.kajo_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    # -- outputs ---------------------------------------------------------------------------
+    def radiance(self) -> np.ndarray:
+        """(H, W, 4) float32: sum over passes of radiance / S (divide by .passes for the estimate)."""
+        out = np.empty((self.height, self.width, 4), np.float32)
+        capi.check(self._L.kajo_hip_read_radiance(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def argb8(self) -> np.ndarray:
+        """(H, W) uint32 ARGB8, sRGB-encoded, row 0 = top (Image::pixels, renderer/Image.h:18-20)."""
+        out = np.empty((self.height, self.width), np.uint32)
+        capi.check(self._L.kajo_hip_resolve_argb8(self._h, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def counters(self) -> dict:
+        c = capi.KajoCounters()
+        capi.check(self._L.kajo_hip_counters(self._h, C.byref(c)))
+        return {k: getattr(c, k) for k, _ in capi.KajoCounters._fields_}
+
+    # -- multi-GPU plumbing ----------------------------------------------------------------
+    def tile_buffer(self):
+        ptr, nbytes = C.c_void_p(), C.c_size_t()
+        capi.check(self._L.kajo_hip_tile_buffer(self._h, C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def compose(self, gathered_device_ptr: int):
+        capi.check(self._L.kajo_hip_compose(self._h, C.c_void_p(gathered_device_ptr)))
+
+
+def stage_scene(scene: Scene):
+    """Host-only: (inverse+determinant per object [n,17], camera basis [4,3]) as create() stages them."""
+    L = capi.lib()
+    n = scene.n_planes + scene.n_spheres
+    inv = np.zeros((n, 17), np.float32)
+    basis = np.zeros((4, 3), np.float32)
+    pod = scene.pod()
+    capi.check(L.kajo_hip_stage_scene(C.byref(pod), inv.ctypes.data_as(C.c_void_p), basis.ctypes.data_as(C.c_void_p)))
+    return inv, basis

@@ -315,6 +315,19 @@ struct alignas(64) Counters // one cache line each: per-thread instances sit in 
     uint64_t paths, traversals, vertices, primitiveTests;
 };
 
+// Optional per-path event log (koracle_debug_path): vertex ids and lobe kinds, for diagnosing a
+// mismatching path. Never set during normal rendering.
+thread_local std::vector<float>* g_pathLog = nullptr;
+inline void logEvent(float code, float a = 0, float b = 0, float c = 0)
+{
+    if (g_pathLog) {
+        g_pathLog->push_back(code);
+        g_pathLog->push_back(a);
+        g_pathLog->push_back(b);
+        g_pathLog->push_back(c);
+    }
+}
+
 struct Hit
 {
     int id; // 0 miss, 1..nPlanes planes, nPlanes+1.. spheres
@@ -639,6 +652,7 @@ struct Oracle
             }
             if (ctr)
                 ctr->vertices++;
+            logEvent(1, (float)sp.id, (float)depth, sp.t);
             const Mat& m = material(sp.id);
             V3 E = collectEmission ? m.emission : v3(0, 0, 0); // :121
 
@@ -663,6 +677,7 @@ struct Oracle
             bool transparent = rng.flipCoin(pTransp, &pt);
 
             if (transparent) { // :137-151
+                logEvent(2, 3);
                 Bsdf f{3, m.specular, m.ior};
                 float pdf;
                 V3 d = bsdfGenerate<M>(f, sp, rng, &pdf);
@@ -688,6 +703,7 @@ struct Oracle
                 f = Bsdf{0, m.diffuse, 0.f}; // :173
             }
             float s = 1 / pc * 1 / pt * 1 / pd;
+            logEvent(2, (float)f.kind, s);
 
             // shadeWithBSDF, :180-215
             V3 Ld = v3(0, 0, 0);
@@ -710,6 +726,7 @@ struct Oracle
                     continue;
                 Ld = Ld + ((1 / (pb + pl) * bsdfEvaluate<M>(f, sp, l)) * std::max(0.f, dot(sp.normal, l))) *
                               light.mat.emission;
+                logEvent(3, pb, pl, Ld.x);
             }
 
             float p;
@@ -734,6 +751,7 @@ struct Oracle
             }
 
             V3 wb = (1 / (pL + p) * bsdfEvaluate<M>(f, sp, d)) * std::max(0.f, dot(sp.normal, d)); // :208-212
+            logEvent(4, p, pL, wb.x);
             L = L + T * (s * (E + Ld));
             T = T * (s * wb);
             collectEmission = false; // SampleNonEmissiveObjects
@@ -1099,6 +1117,31 @@ void koracle_strictmath(int fn, int n, const float* x, const float* y, float* ou
         default: out[i] = kajo_powf(x[i], y[i]); break;
         }
     }
+}
+
+// Event log of ONE camera path (pixel x,y; sample index; pass): records of 4 floats
+// (code, a, b, c): 1 = vertex (id, depth, t), 2 = lobe (kind, s), 3 = light sample kept (pb, pl, Ld.x),
+// 4 = BSDF extension (p, pL, wb.x). Returns the number of floats written (<= cap); rgb gets the path radiance.
+int koracle_debug_path(void* hh, int W, int Hh, int S, int pass, uint64_t seed, int depthLimit, int x, int y,
+                       int sample, float* out, int cap, float* rgb)
+{
+    Handle* H = static_cast<Handle*>(hh);
+    const Oracle& o = *H->o;
+    Oracle::FrameConsts c = Oracle::frameConsts(W, Hh, S);
+    std::vector<float> log;
+    g_pathLog = &log;
+    Rng rng;
+    uint64_t st[2];
+    kajo_stream_state(seed, (uint32_t)pass, (uint32_t)sample, (uint32_t)(y * W + x), st);
+    rng.lo = st[0];
+    rng.hi = st[1];
+    V3 r = H->math ? o.cameraPath<StrictMath>(c, x, y, sample % c.n, sample / c.n, rng, depthLimit, nullptr)
+                   : o.cameraPath<LibmMath>(c, x, y, sample % c.n, sample / c.n, rng, depthLimit, nullptr);
+    g_pathLog = nullptr;
+    st3(rgb, 0, r);
+    int n = (int)std::min<size_t>(log.size(), (size_t)cap);
+    std::memcpy(out, log.data(), n * sizeof(float));
+    return n;
 }
 
 } // extern "C"

@@ -211,3 +211,13 @@ class Handle:
         s = self.L.lib.koracle_render_native(self.h, C.c_int(W), C.c_int(H), C.c_int(passes), C.c_int(threads),
                                              C.c_int(depth_limit), _p(acc))
         return s, acc
+
+
+def debug_path(handle, W, H, S, x, y, sample, npass=1, seed=236367, depth_limit=8):
+    """Oracle only: event log of one camera path (see koracle_debug_path)."""
+    out = np.zeros(4096, np.float32)
+    rgb = np.zeros(3, np.float32)
+    n = handle.L.lib.koracle_debug_path(handle.h, C.c_int(W), C.c_int(H), C.c_int(S), C.c_int(npass), C.c_uint64(seed),
+                                        C.c_int(depth_limit), C.c_int(x), C.c_int(y), C.c_int(sample), _p(out),
+                                        C.c_int(out.size), _p(rgb))
+    return out[:n].reshape(-1, 4), rgb

@@ -1,0 +1,85 @@
+"""CPU-side checks of the C ABI library: it loads, exports exactly what include/kajo_hip.h
+declares, stages scenes like the oracle, validates arguments and refuses to run without a GPU
+(there is no CPU fallback in the product)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kajo_amd import capi
+from kajo_amd.renderer import HipRenderer, stage_scene
+from oraclelib import OracleLib, available
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_header_symbols():
+    L = capi.lib()
+    header = open(os.path.join(ROOT, "include", "kajo_hip.h")).read()
+    declared = set(re.findall(r"\b(kajo_hip_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
+    for name in declared:
+        assert hasattr(L, name), name
+    assert b"gfx950" in L.kajo_hip_version()
+
+
+def test_pod_layout_matches_header():
+    # sizes the C side assumes (include/kajo_scene.h comments)
+    from kajo_amd import scene as S
+    assert C.sizeof(S.KajoMaterial) == 88 and C.sizeof(S.KajoSphere) == 156 and C.sizeof(S.KajoPlane) == 152
+    assert C.sizeof(S.KajoCamera) == 128
+    assert C.sizeof(capi.KajoParams) == 48 and C.sizeof(capi.KajoCounters) == 64
+
+
+@pytest.mark.skipif(not available("oracle"), reason="oracle not built")
+def test_staging_bit_exact_with_oracle(scenes):
+    O = OracleLib("oracle")
+    for key, sc in scenes.items():
+        inv, basis = stage_scene(sc)
+        h = O.create(sc)
+        assert np.array_equal(inv, h.staged(sc.n_planes + sc.n_spheres)), key
+        assert np.array_equal(basis, h.camera_basis()), key
+
+
+def test_staging_matches_golden(golden, scenes):
+    z = golden.kat_basic
+    for key, sc in scenes.items():
+        inv, basis = stage_scene(sc)
+        assert np.array_equal(inv, z[key + "/staged_strict"])
+        assert np.array_equal(basis, z[key + "/basis_strict"])
+
+
+def test_argument_validation(scenes):
+    sc = scenes["spheres_a1"]
+    for kw in (dict(width=0, height=4), dict(width=4, height=-1), dict(spp=0), dict(spp=70000), dict(depth_limit=-1),
+               dict(tile=(12, 16)), dict(tile=(8, 8)), dict(tile_index=2, tile_count=2), dict(tile_count=-1)):
+        args = dict(width=16, height=16)
+        args.update(kw)
+        with pytest.raises(capi.KajoError) as e:
+            HipRenderer(sc, **args)
+        assert e.value.code == -1, (kw, str(e.value))
+
+
+def test_no_cpu_fallback(scenes):
+    """Without a GPU the product must fail loudly, not render on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.KajoError) as e:
+        HipRenderer(scenes["spheres_a1"], 16, 16)
+    assert e.value.code == -3
+    assert "no CPU path" in str(e.value)
+
+
+def test_product_never_imports_oracle():
+    """Nothing under kajo_amd/ may reference oracle/ (the oracle is test infrastructure)."""
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "kajo_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".hpp")) or f == "Makefile":
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                if re.search(r"oracle/|koracle_|kref_|libkajo_oracle|libkajo_ref", text):
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad

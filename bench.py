@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""Benchmark of the HIP backend on the reference's headline workload (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One STEP = one complete frame of the hot path: spheres.json (parsed-scene fixture), 16:9,
+16 passes x S=32 nominal samples (= "512 spp"; 25 camera paths are traced per pixel per pass,
+renderer/cpu/Renderer.cpp:21,38), depth limit 8, MIS on -- BASELINE.json configs[1] -- rendered
+into HBM, gathered to rank 0 (one RCCL gather of the tile buffers when N > 1), composed and
+resolved to ARGB8 on the device. Inputs (the staged scene) are resident in HBM before the timed
+region; nothing is read back to the host inside it.
+
+N = 1: 1920 x 1080. N > 1: weak scaling -- the pixel count grows with N at fixed 16:9 and fixed
+passes, so every GPU keeps 2.07 Mpx x 400 paths of work (N = 4 is the 3840 x 2160 frame of
+configs[2]); tiles are dealt round-robin over the ranks, there is no collective on the data path
+other than the per-frame gather.
+
+value = Msamples/s = camera paths of all ranks / max-over-ranks wall time.
+Rank 0 prints ONE JSON line. The oracle / compiled reference are used ONLY for the cpu_baseline
+and parity legs, never inside the timed region.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PASSES = 16
+SPP = 32
+DEPTH = 8
+SEED = 0o715517
+PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+
+class DevicePtr:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, nfloats):
+        self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 3}
+
+
+def frame_size(n_gpus):
+    if n_gpus == 1:
+        return 1920, 1080
+    s = math.sqrt(n_gpus)
+    w = int(round(1920 * s / 8)) * 8
+    return w, int(round(w * 9 / 16))
+
+
+def flops_per_path(n_planes, n_spheres, traversals_per_path, vertices_per_path):
+    """T * (14 nPlanes + 28 nSpheres) + V * 150."""
+    return traversals_per_path * (14 * n_planes + 28 * n_spheres) + vertices_per_path * 150
+
+
+def cpu_baseline(scene, W, H):
+    """The reference's own hot loop (cpu::Renderer::render on row slices, one std::async per core,
+    renderer/cpu/Scheduler.cpp:32-42) from the compiled reference when oracle/_ref travelled with the
+    snapshot, else this repo's scalar port; on a bounded sample of the same frame."""
+    from oraclelib import OracleLib, available
+
+    cores = os.cpu_count() or 1
+    if available("ref"):
+        kind, h = "reference", OracleLib("ref").create(scene)
+    else:
+        kind, h = "port", OracleLib("oracle").create(scene, 0)
+    t1, _ = h.render_native(W, H, 1, cores)
+    passes = max(1, min(8, int(12.0 / max(t1, 1e-3))))
+    t, _ = h.render_native(W, H, passes, cores)
+    paths = W * H * 25 * passes
+    t1c, _ = h.render_native(W, H // 8, 1, 1)  # one thread, an eighth of the rows
+    return {
+        "value": paths / t / 1e6, "unit": "Msamples/s", "cores": cores, "kind": kind,
+        "sample": "%dx%d, %d pass(es) x 25 paths/px, reference slicing (1 slice per core), %.1f s" % (W, H, passes, t),
+        "one_thread_value": W * (H // 8) * 25 / t1c / 1e6,
+    }
+
+
+def parity_leg(scene, W, H, renderer_factory):
+    """Per-pixel RMSE of the radiance estimate against the CPU oracle on a 256 x 144 frame of the
+    same scene/settings (the oracle needs seconds at this size, hours at 1080p)."""
+    from oraclelib import OracleLib
+
+    w, h, passes = 256, 144, 4
+    want = OracleLib("oracle").create(scene, 0).render(w, h, S=SPP, passes=passes, seed=SEED, depth_limit=DEPTH)[..., :3] / passes
+    r = renderer_factory(w, h)
+    got = r.render(passes).radiance()[..., :3] / passes
+    r.close()
+    m = np.isfinite(got) & np.isfinite(want)
+    d = np.abs(got - want)[m]
+    cl = (np.clip(got, 0, 1) - np.clip(want, 0, 1))[m]
+    return {"frame": "%dx%d, %d passes" % (w, h, passes), "median_abs": float(np.median(d)), "p99_abs": float(np.percentile(d, 99)),
+            "rmse_clamped01": float(np.sqrt(np.mean(cl ** 2))), "nonfinite_px": int((~m).sum() // 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--strict", action="store_true", help="time the STRICT kernels instead of the product path")
+    ap.add_argument("--passes-per-launch", type=int, default=0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the backend has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from kajo_amd.renderer import HipRenderer
+    from kajo_amd.scene import Scene
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+    scene = Scene.from_npz(z, "spheres_a169/", "spheres.json 16:9")
+    W, H = frame_size(world)
+
+    def factory(w, h, **kw):
+        return HipRenderer(scene, w, h, spp=SPP, depth_limit=DEPTH, seed=SEED, strict=args.strict, device=local_rank,
+                           passes_per_launch=args.passes_per_launch, **kw)
+
+    r = factory(W, H, tile_index=rank, tile_count=world)
+    ptr, nbytes = r.tile_buffer()
+    mine = torch.as_tensor(DevicePtr(ptr, nbytes // 4), device="cuda")
+    gathered = None
+    argb = torch.empty(W * H, dtype=torch.int32, device="cuda") if rank == 0 else None
+    if world > 1 and rank == 0:
+        gathered = torch.empty(world * (nbytes // 4), dtype=torch.float32, device="cuda")
+    L = r._L
+
+    def step():
+        r.render(PASSES)
+        r.wait()
+        if world > 1:
+            dist.gather(mine, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                torch.cuda.current_stream().synchronize()
+                r.compose(gathered.data_ptr())
+        if rank == 0:
+            from kajo_amd import capi
+            capi.check(L.kajo_hip_resolve_argb8_device(r._h, C.c_void_p(argb.data_ptr())))
+            r.wait()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    c0 = r.counters()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    c1 = r.counters()
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    n = int(math.sqrt(SPP))
+    paths_per_step = W * H * n * n * PASSES
+    value = paths_per_step * args.steps / dt / 1e6
+
+    out = None
+    if rank == 0:
+        # work per path from the device counters of a separate, untimed frame (deterministic)
+        rc = factory(W, H, tile_index=0, tile_count=world, counters=True)
+        cc = rc.render(PASSES).counters()
+        rc.close()
+        trav = cc["traversals"] / cc["paths"]
+        vert = cc["vertices"] / cc["paths"]
+        fpp = flops_per_path(scene.n_planes, scene.n_spheres, trav, vert)
+        launches = c1["launches"] - c0["launches"]
+        kernel_ms = (c1["kernelMs"] - c0["kernelMs"]) / max(launches, 1)
+        paths_per_launch = (c1["paths"] - c0["paths"]) / max(launches, 1)
+        achieved = fpp * paths_per_launch / (kernel_ms * 1e-3) / 1e12
+        owned_px = (c1["paths"] - c0["paths"]) / (n * n * PASSES * args.steps)
+        hbm_gbs = 32.0 * owned_px / (kernel_ms * 1e-3) / 1e9  # float4 read + write per pixel per launch
+        out = {
+            "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "data/spheres.json (parsed-scene fixture), %dx%d, 512 spp = 16 passes x S=32 "
+                                   "(25 camera paths/px/pass), depth 8, MIS on; BASELINE configs[1]%s" %
+                                   (W, H, "" if world == 1 else " scaled to %d GPUs at 2.07 Mpx per GPU" % world),
+                       "numerics": "strict" if args.strict else "fast", "tiles": "64x16 round-robin over ranks",
+                       "paths_per_step": paths_per_step},
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "kernel": "kajo_render_strict" if args.strict else "kajo_render_fast",
+                         "kernel_ms_per_launch": kernel_ms, "launches_per_step": launches / args.steps,
+                         "flops_per_path": fpp, "traversals_per_path": trav, "vertices_per_path": vert,
+                         "lane_efficiency": cc["traversals"] / max(cc["laneSlots"], 1),
+                         "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
+                                 "algorithmic_bytes_per_launch": 32.0 * owned_px}},
+            "in_kernel_value": paths_per_launch / (kernel_ms * 1e-3) / 1e6 * world,
+            "mtraversals_per_s": value * trav,
+            "nominal_rays_x_spp_x_bounces_per_s_M": W * H * n * n * PASSES * DEPTH * args.steps / dt / 1e6,
+        }
+    r.close()
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(scene, W, H)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        out["parity"] = parity_leg(scene, W, H, factory)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

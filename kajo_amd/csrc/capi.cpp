@@ -22,10 +22,10 @@
 
 // launchers defined next to their kernels (kernel_fast.hip, kernel_strict.hip, aux_kernels.hip)
 extern "C" {
-int kajo_render_fast_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
-int kajo_render_strict_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
-int kajo_render_fast_set_lds(size_t lds);
-int kajo_render_strict_set_lds(size_t lds);
+int kajo_render_fast_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
+int kajo_render_strict_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
+int kajo_render_fast_set_lds(int coldInLds, size_t lds);
+int kajo_render_strict_set_lds(int coldInLds, size_t lds);
 int kajo_resolve_fast_launch(const void* frame, int count, float passes, void* dst, void* stream);
 int kajo_resolve_strict_launch(const void* frame, int count, float passes, void* dst, void* stream);
 int kajo_compose_launch(const void* gathered, const TileMap* map, void* frame, void* stream);
@@ -95,6 +95,7 @@ struct KajoHip
     unsigned long long* counters = nullptr; // device [4]
     int passesDone = 0;
     size_t ldsBytes = 0;
+    int coldInLds = 1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // kernel timing
     std::vector<hipEvent_t> eventPool;
     double kernelMs = 0.0;
@@ -305,13 +306,20 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         v.dp3[i] = st.p3[i] - st.p1[i];
         v.origin[i] = st.origin[i];
     }
-    h->ldsBytes = (size_t)v.nPlanes * (16 + 4) + (size_t)v.nSphereHot * 16 + (size_t)v.nSpheres * 4;
+    // LDS budget per workgroup (device_scene.h / integrator.inc.hip renderBody): hot records always,
+    // cold records too while the total stays small enough for four workgroups per CU (160 KiB / 4).
+    const size_t hotBytes = (size_t)v.nPlanes * (16 + 4) + (size_t)v.nSphereHot * 16 + (size_t)v.nSpheres * 4;
+    const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * 80 +
+                             (size_t)v.nLights * 4;
+    h->coldInLds = hotBytes + coldBytes <= 40 * 1024;
+    h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0);
     if (h->ldsBytes > 160 * 1024) {
         destroy(h);
         return fail(KAJO_E_INVALID, "scene exceeds the 160 KiB LDS staging limit (hot records)");
     }
     if (h->ldsBytes > 48 * 1024) {
-        CREATE_TRY((hipError_t)(h->strict() ? kajo_render_strict_set_lds(h->ldsBytes) : kajo_render_fast_set_lds(h->ldsBytes)));
+        CREATE_TRY((hipError_t)(h->strict() ? kajo_render_strict_set_lds(h->coldInLds, h->ldsBytes)
+                                            : kajo_render_fast_set_lds(h->coldInLds, h->ldsBytes)));
     }
 
     // ---- tiles -----------------------------------------------------------------------------
@@ -413,8 +421,8 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         if ((rc = getEvent(h, &e0)) || (rc = getEvent(h, &e1)))
             return rc;
         HIP_TRY(hipEventRecord(e0, h->stream));
-        hipError_t le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, grid, block, h->ldsBytes, h->stream)
-                                                 : kajo_render_fast_launch(&a, grid, block, h->ldsBytes, h->stream));
+        hipError_t le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, h->ldsBytes, h->stream)
+                                                 : kajo_render_fast_launch(&a, h->coldInLds, grid, block, h->ldsBytes, h->stream));
         if (le != hipSuccess)
             return failHip(le, "render kernel launch");
         HIP_TRY(hipEventRecord(e1, h->stream));

@@ -139,12 +139,20 @@ struct Hit
     float t0;   // object-space parameter of a sphere hit
 };
 
+// Pointers the integrator reads the scene through. The hot records are always in LDS; the cold
+// ones (shading frames, sphere centres, materials, light list) are in LDS too when the whole scene
+// fits the workgroup's budget, else they stay in global memory (L2-resident: a 1000-sphere scene is
+// 200 KiB).
 struct LdsScene
 {
     const DFloat4* planeRow;
     const float* planeDet;
     const DFloat4* sphereHot;
     const uint32_t* sphereHotOffset;
+    const DFloat4* planeFrame;
+    const DSphereCold* sphereCold;
+    const DMaterial* material;
+    const int32_t* light;
 };
 
 KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
@@ -168,15 +176,25 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
 
     const int ns = sc.nSpheres;
     const float aT = dot(d, d); // a of every translated sphere (mat3(inverse) = identity)
+#if !KAJO_STRICT
+    const float iaT = krcp(aT);
+#endif
     for (int i = 0; i < ns; i++) { // Raytracer.cpp:21-72
-        float a, b, c, det;
+        // a t^2 + 2 h t + c = 0 in object space (the reference's b = 2 h); ia = 1 / a
+        float a, h, c, det;
+#if !KAJO_STRICT
+        float ia;
+#endif
         if (sc.allTranslated || !(lds.sphereHotOffset[i] & KAJO_SPHERE_GENERAL)) {
             const DFloat4 s = lds.sphereHot[sc.allTranslated ? i : (int)lds.sphereHotOffset[i]];
             F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
             a = aT;
-            b = 2 * dot(d, o);
+            h = dot(d, o);
             c = dot(o, o) - s.w;
             det = 1.0f;
+#if !KAJO_STRICT
+            ia = iaT;
+#endif
         } else {
             const int k = (int)(lds.sphereHotOffset[i] & ~KAJO_SPHERE_GENERAL);
             const DFloat4 r0 = lds.sphereHot[k], r1 = lds.sphereHot[k + 1], r2 = lds.sphereHot[k + 2];
@@ -186,10 +204,17 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
             F3 o = f3(r0.x * O.x + r0.y * O.y + r0.z * O.z + r0.w * 1.0f, r1.x * O.x + r1.y * O.y + r1.z * O.z + r1.w * 1.0f,
                       r2.x * O.x + r2.y * O.y + r2.z * O.z + r2.w * 1.0f);
             a = dot(dir, dir);
-            b = 2 * dot(dir, o);
+            h = dot(dir, o);
             c = dot(o, o) - q.x;
             det = q.y;
+#if !KAJO_STRICT
+            ia = krcp(a);
+#endif
         }
+#if KAJO_STRICT
+        // Raytracer.cpp:26-44 verbatim: b = 2 dot, discriminant b^2 - 4ac, q by the sign of b,
+        // roots q/a and c/q, sorted
+        float b = 2 * h;
         float discr = b * b - 4 * a * c;
         float sq = ksqrt(discr);
         float q = (b < 0.0f) ? (-b - sq) * .5f : (-b + sq) * .5f;
@@ -197,6 +222,14 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
         float t1 = kdiv(c, q);
         bool sw = t0 > t1;
         float lo = sw ? t1 : t0, hi = sw ? t0 : t1;
+#else
+        // The same two roots (q/a and c/q are the roots of a t^2 + b t + c, by Vieta) as
+        // t = (-h -+ sqrt(h^2 - a c)) / a: one reciprocal per ray instead of two per sphere, no
+        // sort. Differs from the reference's evaluation in the last bits only.
+        float discr = h * h - a * c;
+        float sq = ksqrt(discr);
+        float lo = (-h - sq) * ia, hi = (sq - h) * ia;
+#endif
         float th = (lo < 0.0f) ? hi : lo;
         float ts = th * det;
         bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(ts > tMax || ts < 0.0f);
@@ -230,7 +263,7 @@ KDEV void sphereFrame(F3 n, F3& tg, F3& bn) // Raytracer.cpp:55-65
 KDEV F3 hitNormal(const DSceneView& sc, const LdsScene& lds, const Hit& h, F3 O, F3 d)
 {
     if (h.id <= sc.nPlanes) {
-        const DFloat4 n = sc.planeFrame[3 * (h.id - 1)];
+        const DFloat4 n = lds.planeFrame[3 * (h.id - 1)];
         return f3(n.x, n.y, n.z);
     }
     const int si = h.id - 1 - sc.nPlanes;
@@ -247,7 +280,7 @@ KDEV F3 hitNormal(const DSceneView& sc, const LdsScene& lds, const Hit& h, F3 O,
     F3 o = f3(r0.x * O.x + r0.y * O.y + r0.z * O.z + r0.w * 1.0f, r1.x * O.x + r1.y * O.y + r1.z * O.z + r1.w * 1.0f,
               r2.x * O.x + r2.y * O.y + r2.z * O.z + r2.w * 1.0f);
     F3 n = o + dir * h.t0;
-    const float* m = sc.sphereCold[si].m;
+    const float* m = lds.sphereCold[si].m;
     return normalize(f3(m[0] * n.x + m[1] * n.y + m[2] * n.z, m[3] * n.x + m[4] * n.y + m[5] * n.z,
                         m[6] * n.x + m[7] * n.y + m[8] * n.z));
 }
@@ -407,26 +440,71 @@ enum : int
 
 } // namespace
 
-extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderArgs args)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    const DSceneView& sc = args.scene;
+#ifndef KAJO_WAVES_PER_SIMD
+#define KAJO_WAVES_PER_SIMD 4 // register budget: 512 / 4 = 128 VGPRs per lane
+#endif
 
-    // ---- stage the hot scene records into LDS (one copy per workgroup) --------------------
+namespace
+{
+
+// Workgroup-cooperative copy of `count` 16-byte records into LDS.
+KDEV void stage16(DFloat4* dst, const void* src, int count)
+{
+    const DFloat4* s = static_cast<const DFloat4*>(src);
+    for (int i = threadIdx.x; i < count; i += blockDim.x)
+        dst[i] = s[i];
+}
+
+// COLD_LDS: shading frames, sphere centres, materials and the light list are staged into LDS
+// next to the hot records (scenes up to a few hundred objects); otherwise they are read from
+// global memory.
+template <bool COLD_LDS>
+KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
+{
+    const DSceneView& sc = args.scene;
+    const int np = sc.nPlanes, ns = sc.nSpheres;
+
+    // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
+    // layout: [planeRow np x16][sphereHot nHot x16]{[planeFrame 3np x16][sphereCold ns x64]
+    //         [material (np+ns) x80]}[planeDet np x4][sphereHotOffset ns x4]{[light nL x4]}
     DFloat4* ldsPlaneRow = reinterpret_cast<DFloat4*>(ldsRaw);
-    DFloat4* ldsSphereHot = ldsPlaneRow + sc.nPlanes;
-    float* ldsPlaneDet = reinterpret_cast<float*>(ldsSphereHot + sc.nSphereHot);
-    uint32_t* ldsSphereOff = reinterpret_cast<uint32_t*>(ldsPlaneDet + sc.nPlanes);
-    for (int i = threadIdx.x; i < sc.nPlanes; i += blockDim.x) {
-        ldsPlaneRow[i] = sc.planeRow[i];
-        ldsPlaneDet[i] = sc.planeDet[i];
+    DFloat4* ldsSphereHot = ldsPlaneRow + np;
+    DFloat4* cursor = ldsSphereHot + sc.nSphereHot;
+    stage16(ldsPlaneRow, sc.planeRow, np);
+    stage16(ldsSphereHot, sc.sphereHot, sc.nSphereHot);
+    LdsScene lds;
+    lds.planeRow = ldsPlaneRow;
+    lds.sphereHot = ldsSphereHot;
+    if (COLD_LDS) {
+        DFloat4* f = cursor;
+        DFloat4* c = f + 3 * np;
+        DFloat4* m = c + 4 * ns;
+        cursor = m + 5 * (np + ns);
+        stage16(f, sc.planeFrame, 3 * np);
+        stage16(c, sc.sphereCold, 4 * ns);
+        stage16(m, sc.material, 5 * (np + ns));
+        lds.planeFrame = f;
+        lds.sphereCold = reinterpret_cast<const DSphereCold*>(c);
+        lds.material = reinterpret_cast<const DMaterial*>(m);
+    } else {
+        lds.planeFrame = sc.planeFrame;
+        lds.sphereCold = sc.sphereCold;
+        lds.material = sc.material;
     }
-    for (int i = threadIdx.x; i < sc.nSphereHot; i += blockDim.x)
-        ldsSphereHot[i] = sc.sphereHot[i];
-    for (int i = threadIdx.x; i < sc.nSpheres; i += blockDim.x)
+    float* ldsPlaneDet = reinterpret_cast<float*>(cursor);
+    uint32_t* ldsSphereOff = reinterpret_cast<uint32_t*>(ldsPlaneDet + np);
+    int32_t* ldsLight = reinterpret_cast<int32_t*>(ldsSphereOff + ns);
+    for (int i = threadIdx.x; i < np; i += blockDim.x)
+        ldsPlaneDet[i] = sc.planeDet[i];
+    for (int i = threadIdx.x; i < ns; i += blockDim.x)
         ldsSphereOff[i] = sc.sphereHotOffset[i];
+    if (COLD_LDS)
+        for (int i = threadIdx.x; i < sc.nLights; i += blockDim.x)
+            ldsLight[i] = sc.light[i];
+    lds.planeDet = ldsPlaneDet;
+    lds.sphereHotOffset = ldsSphereOff;
+    lds.light = COLD_LDS ? ldsLight : sc.light;
     __syncthreads();
-    const LdsScene lds{ldsPlaneRow, ldsPlaneDet, ldsSphereHot, ldsSphereOff};
 
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;
@@ -443,13 +521,17 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
     const bool inImage = ownedTile < args.nTilesOwned && px < args.W && py < args.H;
 
     const int n = args.n;
-    const int nn = n * n;
     const uint32_t pixelIndex = (uint32_t)(py * args.W + px);
-    const uint64_t seedKey = args.seed * 0x9E3779B97F4A7C15ull;
+    // include/kajo_stream.h: key words (pixel, sample | pass << 16, seed lo, seed hi) ^ constants
+    const uint32_t keyA = pixelIndex ^ 0x61707865u;
+    const uint32_t keyC = (uint32_t)args.seed ^ 0x79622d32u;
+    const uint32_t keyD = (uint32_t)(args.seed >> 32) ^ 0x6b206574u;
 
     const F3 p1 = ld3(sc.p1), dp2 = ld3(sc.dp2), dp3 = ld3(sc.dp3), origin = ld3(sc.origin);
     const F3 background = ld3(sc.background);
-    const int np = sc.nPlanes;
+    // x * pixelWidth and (H - y) * pixelHeight of Renderer.cpp:56-57 are constants of the lane
+    const float pixX = px * args.pixelWidth;
+    const float pixY = (args.H - py) * args.pixelHeight;
 
     // accumulated radiance of the pixel (Renderer.cpp:70-71), continued across launches
     // (the handle zeroes the buffer when it is created or reset)
@@ -464,7 +546,8 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
     // ---- per-lane path state ----------------------------------------------------------------
     int mode = inImage ? MODE_NEW : MODE_DONE;
     int pass = args.firstPass;
-    int sample = 0;
+    const int lastPass = args.firstPass + args.nPasses; // exclusive
+    int sampleX = 0, sampleY = 0;
     F3 radiance = f3(0.0f, 0.0f, 0.0f); // sum over the pixel's samples of this pass
     Rng rng{0, 0};
     F3 O = origin, d = f3(0.0f, 0.0f, 1.0f);
@@ -485,27 +568,29 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
     const bool counting = args.counters != nullptr;
 
     for (;;) {
-        // ---- MODE_NEW: camera ray of the next sample (Renderer.cpp:55-64) ---------------------
+        // ---- MODE_NEW: camera ray of the next sample (Renderer.cpp:51-64) ---------------------
         if (mode == MODE_NEW) {
-            if (sample == nn) { // pass complete: Renderer.cpp:70-71
+            if (sampleY == n) { // pass complete: Renderer.cpp:70-71
                 total = total + f3(kdiv(radiance.x, args.S), kdiv(radiance.y, args.S), kdiv(radiance.z, args.S));
                 radiance = f3(0.0f, 0.0f, 0.0f);
-                sample = 0;
+                sampleY = 0;
                 pass++;
             }
-            if (pass >= args.firstPass + args.nPasses) {
+            if (pass >= lastPass) {
                 mode = MODE_DONE;
             } else {
-                const int sampleY = sample / n, sampleX = sample - sampleY * n;
-                uint64_t z = seedKey ^ ((uint64_t)(uint32_t)pass << 48) ^ ((uint64_t)(uint32_t)sample << 32) ^
-                             (uint64_t)pixelIndex;
-                rng.lo = kajo_splitmix64(&z);
-                rng.hi = kajo_splitmix64(&z);
+                uint32_t a = keyA, c = keyC, dd = keyD;
+                uint32_t b = ((uint32_t)(sampleY * n + sampleX) | ((uint32_t)pass << 16)) ^ 0x3320646eu;
+                KAJO_QUARTER_ROUND(a, b, c, dd);
+                KAJO_QUARTER_ROUND(a, b, c, dd);
+                KAJO_QUARTER_ROUND(a, b, c, dd);
+                rng.lo = (uint64_t)a | ((uint64_t)b << 32);
+                rng.hi = (uint64_t)c | ((uint64_t)dd << 32);
                 rngStep(rng);
                 float offX = unit(lane32((uint32_t)rng.lo));
                 float offY = unit(lane32((uint32_t)(rng.lo >> 32)));
-                float sx = px * args.pixelWidth + sampleX * args.sampleWidth + offX * args.sampleWidth;
-                float sy = (args.H - py) * args.pixelHeight + sampleY * args.sampleHeight + offY * args.sampleHeight;
+                float sx = pixX + sampleX * args.sampleWidth + offX * args.sampleWidth;
+                float sy = pixY + sampleY * args.sampleHeight + offY * args.sampleHeight;
                 F3 dir = p1 + dp2 * sx + dp3 * sy - origin;
                 d = normalize(dir);
                 O = origin;
@@ -514,7 +599,11 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
                 depth = 0;
                 collectEmission = true;
                 pendBsdf = false;
-                sample++;
+                sampleX++;
+                if (sampleX == n) {
+                    sampleX = 0;
+                    sampleY++;
+                }
                 mode = MODE_EXTEND;
             }
         }
@@ -539,8 +628,8 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
                 float pL = 0.0f;
                 if (hit.id > np && hit.id != vId) {
                     const int si = hit.id - 1 - np;
-                    if (sc.material[hit.id - 1].isLight) {
-                        const DSphereCold& lc = sc.sphereCold[si];
+                    if (lds.material[hit.id - 1].isLight) {
+                        const DSphereCold& lc = lds.sphereCold[si];
                         pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));
                     }
                 }
@@ -555,7 +644,7 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
             } else {
                 if (counting)
                     ctrVertices += 1;
-                const DMaterial& m = sc.material[hit.id - 1];
+                const DMaterial& m = lds.material[hit.id - 1];
                 const F3 view = d;
                 vP = O + d * hit.t; // Raytracer.cpp:134-135
                 vN = hitNormal(sc, lds, hit, O, d);
@@ -597,7 +686,7 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
             }
         } else if (mode == MODE_SHADOW) {
             // Shader.cpp:72-73: the sample counts iff the closest hit of the shadow ray IS the light
-            if (hit.id == np + 1 + sc.light[lightK])
+            if (hit.id == np + 1 + lds.light[lightK])
                 vLd = vLd + pendContrib;
             lightK++;
             sampleNext = true;
@@ -607,12 +696,12 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
             // ---- sampleLights (Shader.cpp:50-86), one light per trip ------------------------------
             bool shadowRay = false;
             while (lightK < sc.nLights) {
-                const int si = sc.light[lightK];
+                const int si = lds.light[lightK];
                 if (np + 1 + si == vId) { // a light does not sample itself
                     lightK++;
                     continue;
                 }
-                const DSphereCold& lc = sc.sphereCold[si];
+                const DSphereCold& lc = lds.sphereCold[si];
                 float pl;
                 const F3 l = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
                 // The reference traces first and asks the BSDF afterwards; a zero BSDF pdf (always for
@@ -623,7 +712,7 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
                     lightK++;
                     continue;
                 }
-                const F3 Le = ld3(sc.material[np + si].emission);
+                const F3 Le = ld3(lds.material[np + si].emission);
                 pendContrib = ((krcp(pb + pl) * bsdfEvaluate(vKind, vColor, vExp, vR, vN, l)) * fmaxf(0.0f, dot(vN, l))) * Le;
                 O = vP + l * kEps;
                 d = l;
@@ -636,7 +725,7 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
                 F3 tg = f3(0.0f, 0.0f, 0.0f), bn = tg;
                 if (vKind == 0) {
                     if (vId <= np) {
-                        const DFloat4 t4 = sc.planeFrame[3 * (vId - 1) + 1], b4 = sc.planeFrame[3 * (vId - 1) + 2];
+                        const DFloat4 t4 = lds.planeFrame[3 * (vId - 1) + 1], b4 = lds.planeFrame[3 * (vId - 1) + 2];
                         tg = f3(t4.x, t4.y, t4.z);
                         bn = f3(b4.x, b4.y, b4.z);
                     } else {
@@ -682,6 +771,22 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KERNEL_NAME(const RenderA
         if (lane == 0)
             atomicAdd(&args.counters[1], v);
     }
+}
+
+} // namespace
+
+// whole scene in LDS
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<true>(args, ldsRaw);
+}
+
+// hot records in LDS, cold ones in global memory (large scenes)
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_BIG(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<false>(args, ldsRaw);
 }
 
 // ---- resolve (Renderer.cpp:73-75 + Image::linearToSRGB / colorToRGBA8, Image.cpp:14-27) ----------

@@ -1,6 +1,7 @@
 // FAST numerics: the product path. Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast
 #define KAJO_STRICT 0
 #define KAJO_KERNEL_NAME kajo_render_fast
+#define KAJO_KERNEL_NAME_BIG kajo_render_fast_big
 #define KAJO_RESOLVE_NAME kajo_resolve_fast
 #include "integrator.inc.hip"
 #include "launch.inc.hip"

@@ -2,18 +2,22 @@
 #define KAJO_CAT2(a, b) a##b
 #define KAJO_CAT(a, b) KAJO_CAT2(a, b)
 
-extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _launch)(const RenderArgs* args, unsigned grid, unsigned block, size_t ldsBytes,
-                                                void* stream)
+// coldInLds: 1 = whole scene staged in LDS (KAJO_KERNEL_NAME), 0 = cold records stay global
+extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _launch)(const RenderArgs* args, int coldInLds, unsigned grid, unsigned block,
+                                                size_t ldsBytes, void* stream)
 {
-    hipLaunchKernelGGL(KAJO_KERNEL_NAME, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
+    if (coldInLds)
+        hipLaunchKernelGGL(KAJO_KERNEL_NAME, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
+    else
+        hipLaunchKernelGGL(KAJO_KERNEL_NAME_BIG, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
     return (int)hipGetLastError();
 }
 
 // dynamic LDS above the 64 KiB default needs an explicit opt-in on the function
-extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(size_t ldsBytes)
+extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(int coldInLds, size_t ldsBytes)
 {
-    return (int)hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    const void* fn = coldInLds ? reinterpret_cast<const void*>(KAJO_KERNEL_NAME) : reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIG);
+    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
 }
 
 extern "C" int KAJO_CAT(KAJO_RESOLVE_NAME, _launch)(const void* frame, int count, float passes, void* dst, void* stream)

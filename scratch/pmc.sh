@@ -1,0 +1,12 @@
+#!/bin/bash
+# PMC passes over the bench (separate runs, --pmc only with kernel-trace): results under gpurun_out/pmc/<tag>/
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+TAG=${1:-v}
+OUT=gpurun_out/pmc/$TAG
+mkdir -p $OUT
+run() { name=$1; shift; rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/$name.log 2>&1; }
+run a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE
+run b SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT
+run c FETCH_SIZE
+run d WRITE_SIZE
+python3 scratch/pmc_summary.py $OUT

@@ -1,0 +1,250 @@
+#include "HipScheduler.h"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <chrono>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "Image.h"
+#include "Preview.h"
+#include "kajo_hip.h"
+#include "scene/Scene.h"
+
+namespace hip
+{
+
+namespace
+{
+
+// C ABI error codes become exceptions on this side of the boundary
+void check(int rc, const char* what)
+{
+    if (rc != KAJO_OK)
+        throw std::runtime_error(std::string(what) + ": " + kajo_hip_last_error());
+}
+
+void checkHip(hipError_t e, const char* what)
+{
+    if (e != hipSuccess)
+        throw std::runtime_error(std::string(what) + ": " + hipGetErrorString(e));
+}
+
+void checkNccl(ncclResult_t r, const char* what)
+{
+    if (r != ncclSuccess)
+        throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
+}
+
+void copyMaterial(const scene::Material& m, KajoMaterial& k)
+{
+    static_assert(sizeof(scene::Material) == sizeof(KajoMaterial), "scene::Material and KajoMaterial share one layout");
+    std::memcpy(&k, &m, sizeof k);
+}
+
+} // namespace
+
+struct Scheduler::Impl
+{
+    Image* image = nullptr;
+    Preview* preview = nullptr;
+    Options opt;
+    std::vector<kajo_hip_t> handles;
+    std::vector<int> devices;
+    std::vector<hipStream_t> streams; // one per owner, shared with its handle
+    std::vector<ncclComm_t> comms;
+    void* gathered = nullptr;         // on device 0: gpus consecutive tile buffers
+    size_t tileBytes = 0;
+    Statistics stats;
+
+    ~Impl()
+    {
+        for (kajo_hip_t h : handles)
+            kajo_hip_destroy(h);
+        for (ncclComm_t c : comms)
+            ncclCommDestroy(c);
+        for (size_t i = 0; i < streams.size(); i++) {
+            (void)hipSetDevice(devices[i]);
+            (void)hipStreamDestroy(streams[i]);
+        }
+        if (gathered) {
+            (void)hipSetDevice(devices.empty() ? 0 : devices[0]);
+            (void)hipFree(gathered);
+        }
+    }
+
+    void create(const scene::Scene& s)
+    {
+        // scene::Scene -> flat POD (valid only during this call, like the reference's const&)
+        std::vector<KajoSphere> spheres(s.spheres.size());
+        std::vector<KajoPlane> planes(s.planes.size());
+        for (size_t i = 0; i < s.spheres.size(); i++) {
+            std::memcpy(spheres[i].transform, s.spheres[i].transform.m, 64);
+            copyMaterial(s.spheres[i].material, spheres[i].material);
+            spheres[i].radius = s.spheres[i].radius;
+        }
+        for (size_t i = 0; i < s.planes.size(); i++) {
+            std::memcpy(planes[i].transform, s.planes[i].transform.m, 64);
+            copyMaterial(s.planes[i].material, planes[i].material);
+        }
+        KajoScene pod;
+        std::memcpy(pod.backgroundColor, &s.backgroundColor, 16);
+        std::memcpy(pod.camera.transform, s.camera.transform.m, 64);
+        std::memcpy(pod.camera.projection, s.camera.projection.m, 64);
+        pod.nSpheres = (int32_t)spheres.size();
+        pod.nPlanes = (int32_t)planes.size();
+        pod.spheres = spheres.data();
+        pod.planes = planes.data();
+
+        if (opt.gpus < 1)
+            throw std::runtime_error("hip::Scheduler: gpus must be >= 1");
+        if (opt.sameDevice && opt.gather != Options::Copy)
+            throw std::runtime_error("hip::Scheduler: sameDevice needs gather = Copy (RCCL wants one rank per device)");
+        for (int g = 0; g < opt.gpus; g++) {
+            KajoParams p;
+            kajo_hip_default_params(&p);
+            p.samplesPerPass = opt.samplesPerPass;
+            p.depthLimit = opt.depthLimit;
+            p.seed = opt.seed;
+            p.flags = (opt.strict ? KAJO_FLAG_STRICT : 0u) | (opt.counters ? KAJO_FLAG_COUNTERS : 0u);
+            p.device = opt.sameDevice ? 0 : g;
+            p.tileIndex = g;
+            p.tileCount = opt.gpus;
+            p.passesPerLaunch = opt.passesPerUpdate;
+            kajo_hip_t h = nullptr;
+            check(kajo_hip_create(&pod, image->width, image->height, &p, &h), "kajo_hip_create");
+            handles.push_back(h);
+            devices.push_back(p.device);
+        }
+        if (opt.gpus > 1) {
+            void* ptr = nullptr;
+            check(kajo_hip_tile_buffer(handles[0], &ptr, &tileBytes), "kajo_hip_tile_buffer");
+            checkHip(hipSetDevice(devices[0]), "hipSetDevice");
+            checkHip(hipMalloc(&gathered, tileBytes * opt.gpus), "hipMalloc(gather buffer)");
+            // one stream per owner carries both its render kernels and its share of the gather
+            for (int g = 0; g < opt.gpus; g++) {
+                checkHip(hipSetDevice(devices[g]), "hipSetDevice");
+                hipStream_t st;
+                checkHip(hipStreamCreateWithFlags(&st, hipStreamNonBlocking), "hipStreamCreate");
+                streams.push_back(st);
+                check(kajo_hip_set_stream(handles[g], st), "kajo_hip_set_stream");
+            }
+            if (opt.gather == Options::Rccl) {
+                comms.resize(opt.gpus);
+                checkNccl(ncclCommInitAll(comms.data(), opt.gpus, devices.data()), "ncclCommInitAll");
+            }
+        }
+    }
+
+    // One exchange per displayed frame: every owner's tile buffer -> GPU 0
+    void gatherAndCompose()
+    {
+        if (opt.gpus == 1)
+            return; // single owner: the library composes from its own tiles
+        const size_t count = tileBytes / sizeof(float);
+        if (opt.gather == Options::Rccl) {
+            checkNccl(ncclGroupStart(), "ncclGroupStart");
+            for (int g = 0; g < opt.gpus; g++) {
+                void* src = nullptr;
+                size_t bytes = 0;
+                check(kajo_hip_tile_buffer(handles[g], &src, &bytes), "kajo_hip_tile_buffer");
+                checkNccl(ncclSend(src, count, ncclFloat, 0, comms[g], streams[g]), "ncclSend");
+                checkNccl(ncclRecv(static_cast<char*>(gathered) + (size_t)g * tileBytes, count, ncclFloat, g, comms[0], streams[0]),
+                          "ncclRecv");
+            }
+            checkNccl(ncclGroupEnd(), "ncclGroupEnd");
+        } else {
+            for (int g = 0; g < opt.gpus; g++) {
+                void* src = nullptr;
+                size_t bytes = 0;
+                check(kajo_hip_tile_buffer(handles[g], &src, &bytes), "kajo_hip_tile_buffer");
+                check(kajo_hip_wait(handles[g]), "kajo_hip_wait");
+                checkHip(hipSetDevice(devices[0]), "hipSetDevice");
+                checkHip(hipMemcpyAsync(static_cast<char*>(gathered) + (size_t)g * tileBytes, src, bytes, hipMemcpyDefault, streams[0]),
+                         "hipMemcpyAsync(gather)");
+            }
+        }
+        check(kajo_hip_compose(handles[0], gathered), "kajo_hip_compose");
+    }
+};
+
+Scheduler::Scheduler(const scene::Scene& scene, Image* image, Preview* preview): Scheduler(scene, image, preview, Options())
+{
+}
+
+Scheduler::Scheduler(const scene::Scene& scene, Image* image, Preview* preview, const Options& options): m_impl(new Impl)
+{
+    m_impl->image = image;
+    m_impl->preview = preview;
+    m_impl->opt = options;
+    m_impl->create(scene);
+}
+
+Scheduler::~Scheduler() {}
+
+const Statistics& Scheduler::statistics() const
+{
+    return m_impl->stats;
+}
+
+void Scheduler::readRadiance(float* dst)
+{
+    check(kajo_hip_read_radiance(m_impl->handles[0], dst), "kajo_hip_read_radiance");
+}
+
+void Scheduler::run()
+{
+    Impl& d = *m_impl;
+    const Options& o = d.opt;
+    const int budget = o.passes > 0 ? o.passes : (d.preview ? 0 : 16);
+    const int batch = o.passesPerUpdate > 0 ? o.passesPerUpdate : 1;
+    const std::thread::id self = std::this_thread::get_id();
+    const auto t0 = std::chrono::steady_clock::now();
+    int done = 0;
+
+    // The SDL calls of the preview stay on this (the main) thread, as the reference requires
+    // (cpu/Scheduler.cpp:64-81 marshals worker progress through a queue for the same reason).
+    while ((!d.preview || d.preview->processEvents()) && (budget == 0 || done < budget)) {
+        const int now = budget == 0 ? batch : (budget - done < batch ? budget - done : batch);
+        for (kajo_hip_t h : d.handles)
+            check(kajo_hip_render(h, now), "kajo_hip_render"); // asynchronous, one stream per GPU
+        for (kajo_hip_t h : d.handles)
+            check(kajo_hip_wait(h), "kajo_hip_wait");
+        done += now;
+        d.gatherAndCompose();
+        check(kajo_hip_resolve_argb8(d.handles[0], d.image->pixels.get()), "kajo_hip_resolve_argb8");
+        if (d.preview)
+            for (int p = done - now + 1; p <= done; p++)
+                d.preview->update(self, p, o.samplesPerPass, 0, 0, d.image->width, d.image->height);
+    }
+
+    d.stats = Statistics();
+    d.stats.passes = done;
+    d.stats.wallSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    for (kajo_hip_t h : d.handles) {
+        KajoCounters c;
+        check(kajo_hip_counters(h, &c), "kajo_hip_counters");
+        d.stats.paths += c.paths;
+        d.stats.traversals += c.traversals;
+        d.stats.vertices += c.vertices;
+        d.stats.laneSlots += c.laneSlots;
+        if (c.kernelMs > d.stats.kernelMs)
+            d.stats.kernelMs = c.kernelMs;
+    }
+}
+
+} // namespace hip
+
+void PassBudgetPreview::update(std::thread::id, int pass, int samples, int, int, int width, int height)
+{
+    m_pass = pass;
+    m_samples += (long long)samples * width * height;
+    if (m_verbose) {
+        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - m_start).count();
+        std::fprintf(stderr, "pass %d  %.2f s  %.1f M nominal samples/s\n", pass, s, m_samples / s / 1e6);
+    }
+}

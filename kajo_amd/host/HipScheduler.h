@@ -1,0 +1,73 @@
+// HipScheduler.h -- the "-r hip" backend behind Kajo's Scheduler plugin interface.
+//
+// Drop-in counterpart of cpu::Scheduler (renderer/cpu/Scheduler.h:22-34, .cpp:53-85): same
+// constructor shape (const scene::Scene&, Image*, Preview*), same single blocking run(). Where the
+// CPU backend cuts the image into one row slice per core and renders them with std::async
+// (cpu/Scheduler.cpp:32-42), this one deals fixed-size tiles round-robin to the node's GPUs, runs
+// one libkajo_hip handle per GPU (include/kajo_hip.h), gathers the tile buffers to GPU 0 once per
+// displayed frame (RCCL over xGMI) and resolves into Image::pixels. The scene is only read inside
+// the constructor, as in the reference (cpu/Scene.cpp:29-38 copies it).
+#ifndef KAJO_HIP_SCHEDULER_H
+#define KAJO_HIP_SCHEDULER_H
+
+#include <cstdint>
+#include <memory>
+
+#include "Scheduler.h"
+
+class Image;
+class Preview;
+
+namespace scene
+{
+class Scene;
+}
+
+namespace hip
+{
+
+struct Options
+{
+    int samplesPerPass = 32;      // m_samples, renderer/cpu/Renderer.cpp:21
+    int depthLimit = 8;           // g_depthLimit, renderer/cpu/Shader.cpp:24
+    uint64_t seed = 0715517;      // renderer/cpu/Random.h:43
+    int passes = 0;               // stop after this many passes; 0 = until the preview closes
+                                  // (16 when there is no preview: the reference never stops by itself)
+    int passesPerUpdate = 1;      // passes rendered between two image/preview refreshes
+    int gpus = 1;                 // devices 0 .. gpus-1
+    bool strict = false;          // STRICT numerics (bit-identical to the CPU oracle)
+    bool counters = false;
+    enum Gather { Rccl, Copy } gather = Rccl; // Copy: hipMemcpyAsync instead of RCCL (also lets
+                                              // several tile owners share ONE device, for tests)
+    bool sameDevice = false;      // all tile owners on device 0 (needs gather = Copy)
+};
+
+struct Statistics
+{
+    int passes = 0;
+    unsigned long long paths = 0, traversals = 0, vertices = 0, laneSlots = 0;
+    double kernelMs = 0;   // max over GPUs of the summed render-kernel time
+    double wallSeconds = 0;
+};
+
+class Scheduler : public ::Scheduler
+{
+public:
+    Scheduler(const scene::Scene&, Image*, Preview*);
+    Scheduler(const scene::Scene&, Image*, Preview*, const Options&);
+    ~Scheduler() override;
+
+    void run() override;
+
+    const Statistics& statistics() const;
+    // whole-frame float accumulation (W*H*4, sum over passes of radiance / S) after run()
+    void readRadiance(float* dst);
+
+private:
+    struct Impl;
+    std::unique_ptr<Impl> m_impl;
+};
+
+} // namespace hip
+
+#endif

@@ -1,0 +1,114 @@
+// Main.cpp -- headless driver with the reference's command line (renderer/Main.cpp:97-146):
+//   kajo_render [-w SIZE] [-h SIZE] [-r hip] [options] SCENE.json     (no SCENE: the built-in test scene)
+// plus what a window-less run needs: a pass budget, an output name and the backend's options.
+#include <cstdio>
+#include <cstdlib>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "HipScheduler.h"
+#include "Image.h"
+#include "Preview.h"
+#include "scene/Parser.h"
+#include "scene/Scene.h"
+
+int main(int argc, char** argv)
+{
+    std::vector<std::string> args(argv, argv + argc);
+    std::string rendererName = "hip", out = "out.png", rawOut, scenePath;
+    int width = 640, height = 480;
+    hip::Options opt;
+    opt.passes = 16;
+    bool verbose = false, json = false;
+    for (size_t i = 1; i < args.size(); i++) {
+        bool more = i + 1 < args.size();
+        const std::string& a = args[i];
+        if (a == "--help") {
+            std::printf("Usage: %s OPTIONS [SCENE]\n\n"
+                        "    -w SIZE         image width (640)\n"
+                        "    -h SIZE         image height (480)\n"
+                        "    -r NAME         renderer (hip)\n"
+                        "    --spp N         nominal samples per pixel per pass (32)\n"
+                        "    --passes N      passes to render (16)\n"
+                        "    --bounces N     depth limit (8)\n"
+                        "    --seed N        stream seed (236367)\n"
+                        "    --gpus N        GPUs to tile the frame over (1)\n"
+                        "    --batch N       passes per image refresh (1)\n"
+                        "    --strict        strict numerics\n"
+                        "    --gather MODE   rccl | copy (multi-GPU gather transport)\n"
+                        "    --same-device   put every tile owner on GPU 0 (testing; implies --gather copy)\n"
+                        "    -o FILE         PNG output (out.png)\n"
+                        "    --raw FILE      also dump the float4 accumulation (W*H*4 floats)\n"
+                        "    --json          print run statistics as one JSON line\n"
+                        "    -v              progress on stderr\n",
+                        args[0].c_str());
+            return 1;
+        } else if (a == "-w" && more) width = std::atoi(args[++i].c_str());
+        else if (a == "-h" && more) height = std::atoi(args[++i].c_str());
+        else if (a == "-r" && more) rendererName = args[++i];
+        else if (a == "--spp" && more) opt.samplesPerPass = std::atoi(args[++i].c_str());
+        else if (a == "--passes" && more) opt.passes = std::atoi(args[++i].c_str());
+        else if (a == "--bounces" && more) opt.depthLimit = std::atoi(args[++i].c_str());
+        else if (a == "--seed" && more) opt.seed = std::strtoull(args[++i].c_str(), nullptr, 0);
+        else if (a == "--gpus" && more) opt.gpus = std::atoi(args[++i].c_str());
+        else if (a == "--batch" && more) opt.passesPerUpdate = std::atoi(args[++i].c_str());
+        else if (a == "--strict") opt.strict = true;
+        else if (a == "--gather" && more) opt.gather = args[++i] == "copy" ? hip::Options::Copy : hip::Options::Rccl;
+        else if (a == "--same-device") { opt.sameDevice = true; opt.gather = hip::Options::Copy; }
+        else if (a == "-o" && more) out = args[++i];
+        else if (a == "--raw" && more) rawOut = args[++i];
+        else if (a == "--json") json = true;
+        else if (a == "-v") verbose = true;
+        else if (!a.empty() && a[0] != '-') scenePath = a;
+    }
+    if (width <= 0 || height <= 0) {
+        std::cerr << "Bad image size" << std::endl;
+        return 1;
+    }
+
+    scene::Scene scene;
+    if (scenePath.empty())
+        scene::buildTestScene(scene);
+    else if (!scene::Parser::load(scene, scenePath, static_cast<float>(width) / height)) {
+        std::cerr << "Failed to parse scene from " << scenePath << std::endl;
+        return 1;
+    }
+
+    std::unique_ptr<Image> image(new Image(width, height));
+    std::unique_ptr<Preview> preview(new PassBudgetPreview(opt.passes, verbose));
+    std::unique_ptr<Scheduler> scheduler;
+    hip::Scheduler* hipScheduler = nullptr;
+    opt.counters = json;
+    try {
+        if (rendererName == "hip") {
+            hipScheduler = new hip::Scheduler(scene, image.get(), preview.get(), opt);
+            scheduler.reset(hipScheduler);
+        } else {
+            std::cerr << "Unknown renderer: " << rendererName << std::endl;
+            return 1;
+        }
+        scheduler->run();
+        if (!rawOut.empty()) {
+            std::vector<float> acc((size_t)width * height * 4);
+            hipScheduler->readRadiance(acc.data());
+            std::ofstream f(rawOut, std::ios::binary);
+            f.write(reinterpret_cast<const char*>(acc.data()), (std::streamsize)(acc.size() * sizeof(float)));
+        }
+    } catch (const std::exception& e) {
+        std::cerr << "kajo_render: " << e.what() << std::endl;
+        return 2;
+    }
+    if (!out.empty() && !image->save(out))
+        return 3;
+    if (json) {
+        const hip::Statistics& s = hipScheduler->statistics();
+        std::printf("{\"width\": %d, \"height\": %d, \"passes\": %d, \"gpus\": %d, \"paths\": %llu, \"traversals\": %llu, "
+                    "\"vertices\": %llu, \"wall_s\": %.6f, \"kernel_ms\": %.3f, \"msamples_per_s\": %.2f}\n",
+                    width, height, s.passes, opt.gpus, s.paths, s.traversals, s.vertices, s.wallSeconds, s.kernelMs,
+                    s.paths / s.wallSeconds / 1e6);
+    }
+    return 0;
+}

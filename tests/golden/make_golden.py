@@ -63,16 +63,26 @@ def main():
 
     # ---- (1) parsed scenes -------------------------------------------------------------
     scenes = {}
-    cases = [("spheres_a1", "data/spheres.json", 1.0), ("spheres_a169", "data/spheres.json", 1920.0 / 1080.0),
-             ("spheres_a43", "data/spheres.json", 640.0 / 480.0), ("test_a1", "data/test.json", 1.0)]
+    # the reference's own scene files, and this repo's scene files (kajo_amd/data) parsed BY THE
+    # REFERENCE'S PARSER: the expected output of the host-side loader (kajo_amd/host/scene/Parser.cpp)
+    own = os.path.join(ROOT, "kajo_amd", "data")
+    cases = [("spheres_a1", os.path.join(REF, "data/spheres.json"), 1.0),
+             ("spheres_a169", os.path.join(REF, "data/spheres.json"), 1920.0 / 1080.0),
+             ("spheres_a43", os.path.join(REF, "data/spheres.json"), 640.0 / 480.0),
+             ("test_a1", os.path.join(REF, "data/test.json"), 1.0),
+             ("caustics_a169", os.path.join(own, "caustics.json"), 1920.0 / 1080.0),
+             ("dialect_a1", os.path.join(own, "dialect.json"), 1.0)]
     out = {}
-    for key, rel, aspect in cases:
-        h = fast.create_from_file(os.path.join(REF, rel), aspect)
+    for key, path, aspect in cases:
+        h = fast.create_from_file(path, aspect)
         sc = h.export_scene(key)
         scenes[key] = sc
         out.update(sc.to_npz_dict(key + "/"))
         h.close()
-    out["meta"] = json.dumps({"cases": [[k, r, a] for k, r, a in cases],
+        h = strict.create_from_file(path, aspect)
+        out.update(h.export_scene(key).to_npz_dict(key + "/strict_"))
+        h.close()
+    out["meta"] = json.dumps({"cases": [[k, os.path.basename(r), a] for k, r, a in cases],
                               "source": "scene::Parser::load (scene/Parser.cpp:214-232), fast build"})
     np.savez_compressed(os.path.join(HERE, "scenes.npz"), **out)
 

@@ -1,0 +1,78 @@
+"""GPU test of the C++ host side (kajo_amd/host): hip::Scheduler behind Kajo's Scheduler interface,
+driven by the headless kajo_render binary, must give exactly the frame the C ABI gives directly."""
+import json
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from kajo_amd.renderer import HipRenderer
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "kajo_amd", "host", "kajo_render")
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(BIN), reason="kajo_render not built")]
+
+
+def read_png(path):
+    data = open(path, "rb").read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, w, h = 8, b"", 0, 0
+    while pos < len(data):
+        n, typ = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        assert zlib.crc32(typ + body) == struct.unpack(">I", data[pos + 8 + n:pos + 12 + n])[0]
+        if typ == b"IHDR":
+            w, h, depth, ctype = struct.unpack(">IIBB", body[:10])
+            assert depth == 8 and ctype == 6
+        elif typ == b"IDAT":
+            idat += body
+        pos += 12 + n
+    raw = np.frombuffer(zlib.decompress(idat), np.uint8).reshape(h, 1 + 4 * w)
+    assert (raw[:, 0] == 0).all()
+    return raw[:, 1:].reshape(h, w, 4)
+
+
+def run(tmp_path, *extra):
+    out, raw = str(tmp_path / "o.png"), str(tmp_path / "o.raw")
+    cmd = [BIN, "-w", "96", "-h", "54", "-r", "hip", "--passes", "2", "-o", out, "--raw", raw, "--json", *extra,
+           os.path.join(ROOT, "kajo_amd", "data", "caustics.json")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stderr
+    stats = json.loads(p.stdout.strip().splitlines()[-1])
+    return np.fromfile(raw, np.float32).reshape(54, 96, 4), read_png(out), stats
+
+
+def test_driver_matches_c_abi(tmp_path, scenes):
+    acc, png, stats = run(tmp_path)
+    assert stats["passes"] == 2 and stats["paths"] == 96 * 54 * 25 * 2
+    sc = scenes["caustics_a169"]
+    from kajo_amd.scene import Scene
+    import numpy as _np
+    z = _np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+    strict_parse = Scene.from_npz(z, "caustics_a169/strict_")  # what the host loader produces, bit for bit
+    with HipRenderer(strict_parse, 96, 54) as r:
+        want = r.render(2).radiance()
+        px = r.argb8()
+    assert np.array_equal(acc.view(np.uint32), want.view(np.uint32))
+    # PNG bytes are R, G, B, A of the ARGB8 pixels (renderer/Image.cpp:34-38)
+    assert np.array_equal(png[..., 0], (px >> 16) & 255) and np.array_equal(png[..., 1], (px >> 8) & 255)
+    assert np.array_equal(png[..., 2], px & 255) and (png[..., 3] == 255).all()
+
+
+@pytest.mark.parametrize("extra", [("--gpus", "2", "--same-device"), ("--gpus", "3", "--same-device", "--batch", "2"), ("--batch", "2")])
+def test_tile_owners_and_batching_do_not_change_the_frame(tmp_path, extra):
+    base, _, _ = run(tmp_path)
+    acc, _, _ = run(tmp_path, *extra)
+    assert np.array_equal(acc.view(np.uint32), base.view(np.uint32))
+
+
+def test_unknown_renderer_and_bad_scene(tmp_path):
+    p = subprocess.run([BIN, "-r", "gl"], capture_output=True, text=True)
+    assert p.returncode == 1 and "Unknown renderer" in p.stderr   # renderer/Main.cpp:139-142
+    bad = tmp_path / "bad.json"
+    bad.write_text("[]")
+    p = subprocess.run([BIN, str(bad)], capture_output=True, text=True)
+    assert p.returncode == 1 and "Failed to parse scene" in p.stderr  # renderer/Main.cpp:126-129

@@ -133,6 +133,7 @@ def main():
 
     from kajo_amd.renderer import HipRenderer
     from kajo_amd.scene import Scene
+    from kajo_amd.tiles import gather_to_root
 
     z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
     scene = Scene.from_npz(z, "spheres_a169/", "spheres.json 16:9")
@@ -155,7 +156,7 @@ def main():
         r.render(PASSES)
         r.wait()
         if world > 1:
-            dist.gather(mine, list(gathered.chunk(world)) if rank == 0 else None, dst=0)
+            gather_to_root(dist, mine, gathered, rank, world)
             if rank == 0:
                 torch.cuda.current_stream().synchronize()
                 r.compose(gathered.data_ptr())

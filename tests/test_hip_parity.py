@@ -101,13 +101,17 @@ def test_tiling_is_bit_invariant(scenes, count):
         for i, p in enumerate(parts):
             p.render(1).wait()
             ptr, _ = p.tile_buffer()
-            src = torch.empty(0)
             hip = C.CDLL("libamdhip64.so")
             rc = hip.hipMemcpy(C.c_void_p(gathered.data_ptr() + i * nbytes), C.c_void_p(ptr), C.c_size_t(nbytes), C.c_int(3))
             assert rc == 0
         parts[0].compose(gathered.data_ptr())
         got = parts[0].radiance()
         assert bits_equal(got, want), (count, strict)
+        # the host-side mirror of the tile map (kajo_amd/tiles.py, used for the gloo test) agrees
+        from kajo_amd.tiles import TileLayout
+        lay = TileLayout(W, H, count, (32, 8))
+        assert lay.slots_per_owner * 16 == nbytes
+        assert bits_equal(lay.compose(gathered.cpu().view(count, lay.slots_per_owner, 4).numpy()), want)
         for p in parts:
             p.close()
 

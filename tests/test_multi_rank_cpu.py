@@ -1,0 +1,74 @@
+"""The N > 1 path on the CPU: two gloo ranks deal the tiles, fill their compact buffers, gather to
+rank 0 and compose -- every pixel must come back from the rank and slot the device code would use."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, W, H, tile, out_path):
+    sys.path.insert(0, ROOT)
+    from kajo_amd.tiles import TileLayout, gather_to_root
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lay = TileLayout(W, H, world, tile)
+    # what a rank's render kernel leaves in its buffer: float4 per slot; here the pixel's own identity
+    local = torch.full((lay.slots_per_owner * 4,), -1.0)
+    ys, xs = np.mgrid[0:H, 0:W]
+    owner, slot = lay.owner_and_slot(xs, ys)
+    mine = owner == rank
+    buf = local.view(-1, 4).numpy()
+    buf[slot[mine], 0] = xs[mine]
+    buf[slot[mine], 1] = ys[mine]
+    buf[slot[mine], 2] = rank
+    buf[slot[mine], 3] = 1.0
+    gathered = torch.empty(world * local.numel()) if rank == 0 else None
+    gather_to_root(dist, local, gathered, rank, world)
+    if rank == 0:
+        frame = lay.compose(gathered.view(world, lay.slots_per_owner, 4).numpy())
+        np.save(out_path, frame)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("W,H,tile,world", [(200, 70, (32, 8), 2), (1920 // 8, 1080 // 8, (64, 16), 2), (97, 33, (64, 16), 3)])
+def test_gloo_gather_and_compose(tmp_path, W, H, tile, world):
+    out = str(tmp_path / "frame.npy")
+    mp.spawn(_worker, args=(world, _free_port(), W, H, tile, out), nprocs=world, join=True)
+    frame = np.load(out)
+    ys, xs = np.mgrid[0:H, 0:W]
+    assert np.array_equal(frame[..., 0], xs) and np.array_equal(frame[..., 1], ys)
+    assert (frame[..., 3] == 1.0).all()
+    # round-robin dealing: tile t belongs to rank t % world
+    tiles_x = -(-W // tile[0])
+    want_owner = ((ys // tile[1]) * tiles_x + xs // tile[0]) % world
+    assert np.array_equal(frame[..., 2], want_owner)
+
+
+def test_layout_matches_library_sizes():
+    """slots_per_owner must equal what kajo_hip_create allocates (capi.cpp) -- checked through the
+    C ABI on the GPU in tests/test_hip_parity.py::test_tiling_is_bit_invariant; here the arithmetic."""
+    from kajo_amd.tiles import TileLayout
+    lay = TileLayout(1920, 1080, 8)
+    assert lay.tiles_x == 30 and lay.tiles_y == 68 and lay.n_tiles == 2040
+    assert lay.tiles_per_owner == 255 and lay.slots_per_owner == 255 * 1024
+    assert sum(lay.owned_pixels(r) for r in range(8)) == 1920 * 1080
+    # balance: no rank owns more than 1 % above the mean
+    px = [lay.owned_pixels(r) for r in range(8)]
+    assert max(px) <= 1.01 * (1920 * 1080 / 8)

@@ -299,6 +299,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     v.nSphereHot = (int)st.sphereHot.size();
     v.nLights = (int)st.light.size();
     v.allTranslated = st.allTranslated;
+    v.planesRigid = st.planesRigid;
     for (int i = 0; i < 3; i++) {
         v.background[i] = st.background[i];
         v.p1[i] = st.p1[i];
@@ -341,8 +342,8 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     CREATE_TRY(hipMalloc(&h->tiles, h->tileBytes));
     CREATE_TRY(hipMemsetAsync(h->tiles, 0, h->tileBytes, h->stream));
     if (p.flags & KAJO_FLAG_COUNTERS) {
-        CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->counters), 4 * sizeof(unsigned long long)));
-        CREATE_TRY(hipMemsetAsync(h->counters, 0, 4 * sizeof(unsigned long long), h->stream));
+        CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->counters), 32 * sizeof(unsigned long long)));
+        CREATE_TRY(hipMemsetAsync(h->counters, 0, 32 * sizeof(unsigned long long), h->stream));
     }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
@@ -455,7 +456,7 @@ int kajo_hip_reset(kajo_hip_t h)
         return rc;
     HIP_TRY(hipMemsetAsync(h->tiles, 0, h->tileBytes, h->stream));
     if (h->counters)
-        HIP_TRY(hipMemsetAsync(h->counters, 0, 4 * sizeof(unsigned long long), h->stream));
+        HIP_TRY(hipMemsetAsync(h->counters, 0, 32 * sizeof(unsigned long long), h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->passesDone = 0;
     h->frameValid = false;
@@ -533,6 +534,18 @@ int kajo_hip_read_radiance(kajo_hip_t h, float* dst)
         return rc;
     HIP_TRY(hipMemcpyAsync(dst, h->frame, (size_t)h->W * h->H * 16, hipMemcpyDeviceToHost, h->stream));
     return kajo_hip_wait(h);
+}
+
+// Diagnostic builds only (-DKAJO_PROFILE): 28 raw block-profile words (16 block counts, 5 stamp sums, spare) behind the work counters.
+extern "C" int kajo_hip_debug_profile(kajo_hip_t h, unsigned long long* out28)
+{
+    if (!h || !out28 || !h->counters)
+        return fail(KAJO_E_INVALID, "no counters");
+    int rc = kajo_hip_wait(h);
+    if (rc)
+        return rc;
+    HIP_TRY(hipMemcpy(out28, h->counters + 4, 28 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return KAJO_OK;
 }
 
 int kajo_hip_counters(kajo_hip_t h, KajoCounters* out)

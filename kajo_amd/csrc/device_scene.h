@@ -49,7 +49,8 @@ struct DSphereCold // 16 floats
     float cx, cy, cz, radius;
     float m[9];     // mat3(M), m[3*row + col]: world = m * object
     uint32_t general;
-    float pad[2];
+    float invRadius;    // 1 / radius                       (FAST numerics only)
+    float invTwoPiR2;   // 1 / (2 pi radius^2): light pdf    (FAST numerics only)
 };
 
 // sphereHotOffset[i]: index of the sphere's first float4 in the hot array; bit 31 set = general
@@ -67,6 +68,7 @@ struct DSceneView // device pointers + counts, passed to the kernels by value
     const int32_t* light;       // [nLights] sphere indices, scene order
     int32_t nPlanes, nSpheres, nSphereHot, nLights;
     int32_t allTranslated;      // every sphere uses the 1-float4 record
+    int32_t planesRigid;        // every plane has determinant exactly 1
     float background[3];
     // camera (Renderer.cpp:29-34): p1, p2 - p1, p3 - p1, origin
     float p1[3], dp2[3], dp3[3], origin[3];

@@ -162,6 +162,20 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     float bestT0 = 0.0f;
 
     const int np = sc.nPlanes;
+#if !KAJO_STRICT
+    if (sc.planesRigid) {
+        // det == 1 for every plane: t * det == t and the second sign test repeats the first
+        for (int i = 0; i < np; i++) {
+            const DFloat4 r = lds.planeRow[i];
+            float denom = r.x * d.x + r.y * d.y + r.z * d.z;
+            float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w;
+            float t = -oy * __builtin_amdgcn_rcpf(denom);
+            bool ok = !(__builtin_fabsf(denom) < kFltEpsilon) && !(t < 0.0f) && !(t > tMax);
+            tMax = ok ? t : tMax;
+            best = ok ? i + 1 : best;
+        }
+    } else
+#endif
     for (int i = 0; i < np; i++) { // Raytracer.cpp:74-98; only row y of the inverse matters
         const DFloat4 r = lds.planeRow[i];
         const float det = lds.planeDet[i];
@@ -178,6 +192,25 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     const float aT = dot(d, d); // a of every translated sphere (mat3(inverse) = identity)
 #if !KAJO_STRICT
     const float iaT = krcp(aT);
+    if (sc.allTranslated) {
+        // every sphere is (centre, radius): a = d.d is one value per ray; the two roots are
+        // (-h -+ sqrt(h^2 - a c)) / a
+        for (int i = 0; i < ns; i++) {
+            const DFloat4 s = lds.sphereHot[i];
+            F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+            float h = dot(d, o);
+            float c = dot(o, o) - s.w;
+            float discr = h * h - aT * c;
+            float sq = __builtin_amdgcn_sqrtf(discr);
+            float lo = (-h - sq) * iaT, hi = (sq - h) * iaT;
+            float th = (lo < 0.0f) ? hi : lo;
+            bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(th > tMax);
+            tMax = ok ? th : tMax;
+            best = ok ? np + 1 + i : best;
+            bestT0 = ok ? th : bestT0;
+        }
+        return Hit{best, tMax, bestT0};
+    }
 #endif
     for (int i = 0; i < ns; i++) { // Raytracer.cpp:21-72
         // a t^2 + 2 h t + c = 0 in object space (the reference's b = 2 h); ia = 1 / a
@@ -269,9 +302,16 @@ KDEV F3 hitNormal(const DSceneView& sc, const LdsScene& lds, const Hit& h, F3 O,
     const int si = h.id - 1 - sc.nPlanes;
     const uint32_t off = sc.allTranslated ? (uint32_t)si : lds.sphereHotOffset[si];
     if (!(off & KAJO_SPHERE_GENERAL)) {
+#if KAJO_STRICT
         const DFloat4 s = lds.sphereHot[off];
         F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
         return normalize(o + d * h.t0); // mat3(M) = identity
+#else
+        // the hit point minus the centre has length r: scale instead of normalising
+        const DSphereCold& sc_ = lds.sphereCold[si];
+        F3 o = f3(O.x - sc_.cx, O.y - sc_.cy, O.z - sc_.cz);
+        return (o + d * h.t0) * sc_.invRadius;
+#endif
     }
     const int k = (int)(off & ~KAJO_SPHERE_GENERAL);
     const DFloat4 r0 = lds.sphereHot[k], r1 = lds.sphereHot[k + 1], r2 = lds.sphereHot[k + 2];
@@ -408,6 +448,20 @@ KDEV float solidAngle(F3 centre, float radius, F3 P)
 #endif
 }
 
+#if !KAJO_STRICT
+// 1 / solidAngle without forming the angle: with x = r / dist,
+// 1 / (2 pi (1 - cos asin x)) = (1 + sqrt(1 - x^2)) / (2 pi x^2) = (1 + sqrt(1 - r^2/d^2)) d^2 / (2 pi r^2)
+KDEV float lightPdf(const DSphereCold& lc, F3 P)
+{
+    F3 v = f3(lc.cx - P.x, lc.cy - P.y, lc.cz - P.z);
+    float d2 = dot(v, v);
+    float r2 = lc.radius * lc.radius;
+    float x2 = r2 * __builtin_amdgcn_rcpf(d2);
+    float p = (1.0f + __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - x2))) * d2 * lc.invTwoPiR2;
+    return d2 < r2 ? 0.07957747154594767f : p; // inside the light: 1 / (4 pi)
+}
+#endif
+
 KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
 {
     rngStep(rng);
@@ -425,7 +479,9 @@ KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
     float z = ksqrt(radius * radius - x * x - y * y) * __builtin_amdgcn_sinf((s3 - .5f) * .5f);
 #endif
     F3 dir = normalize(centre + f3(x, y, z) - P);
+#if KAJO_STRICT
     pdf = krcp(solidAngle(centre, radius, P));
+#endif
     return dir;
 }
 
@@ -561,14 +617,48 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     F3 pendContrib = L; // light sample's contribution if its shadow ray reaches the light
     // extension ray sampled from the BSDF: weight pieces that wait for the light pdf of the hit
     bool pendBsdf = false;
-    F3 pendF = L;
+    F3 pendF = L, pendT = L;
     float pendCos = 0.0f, pendP = 0.0f;
 
     unsigned long long ctrTraversals = 0, ctrVertices = 0, ctrSlots = 0;
     const bool counting = args.counters != nullptr;
+#ifdef KAJO_PROFILE
+    // block profile: prof[2k] = wave executions of block k, prof[2k+1] = lanes active in it
+    unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stampSum[5] = {0, 0, 0, 0, 0};
+    unsigned long long stampLast = 0;
+#define KAJO_STAMP(k)                                                                                                  \
+    do {                                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        const unsigned long long now_ = __builtin_amdgcn_s_memtime();                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                             \
+        stampSum[k] += now_ - stampLast;                                                                               \
+        stampLast = now_;                                                                                              \
+    } while (0)
+#define KAJO_PROF(k, cond)                                                                                             \
+    do {                                                                                                               \
+        const unsigned long long m_ = __ballot(cond);                                                                  \
+        if (m_) {                                                                                                      \
+            prof[2 * (k)] += 1;                                                                                        \
+            prof[2 * (k) + 1] += __builtin_popcountll(m_);                                                             \
+        }                                                                                                              \
+    } while (0)
+#else
+#define KAJO_PROF(k, cond)                                                                                             \
+    do {                                                                                                               \
+    } while (0)
+#define KAJO_STAMP(k)                                                                                                  \
+    do {                                                                                                               \
+    } while (0)
+#endif
 
+#ifdef KAJO_PROFILE
+    stampLast = __builtin_amdgcn_s_memtime();
+#endif
     for (;;) {
+        KAJO_STAMP(4); // tail of the previous trip (path bookkeeping, loop back-edge)
         // ---- MODE_NEW: camera ray of the next sample (Renderer.cpp:51-64) ---------------------
+        KAJO_PROF(0, mode == MODE_NEW);
         if (mode == MODE_NEW) {
             if (sampleY == n) { // pass complete: Renderer.cpp:70-71
                 total = total + f3(kdiv(radiance.x, args.S), kdiv(radiance.y, args.S), kdiv(radiance.z, args.S));
@@ -612,8 +702,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         if (activeMask == 0ull)
             break;
 
+        KAJO_STAMP(0); // camera-ray block
         // ---- one ray per lane through the whole scene ------------------------------------------
         const Hit hit = trace(sc, lds, O, d);
+        KAJO_STAMP(1); // traversal
         if (counting) {
             ctrTraversals += __builtin_popcountll(activeMask);
             ctrSlots += 64;
@@ -621,20 +713,25 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
         bool sampleNext = false; // continue with the light loop / BSDF sampling of vertex v*
         bool pathDone = false;
+        KAJO_PROF(1, mode == MODE_EXTEND && pendBsdf && hit.id > np);
+        KAJO_PROF(2, mode == MODE_EXTEND && hit.id != 0);
+        KAJO_PROF(6, mode == MODE_SHADOW);
 
         if (mode == MODE_EXTEND) {
-            // weight of the BSDF-sampled segment that just ended (Shader.cpp:203-212)
+            // Weight of the BSDF-sampled segment that just ended (Shader.cpp:203-212). The throughput was
+            // advanced with a zero light pdf when the direction was sampled (0 + p == p exactly); only a ray
+            // that lands on a light other than the vertex it left needs the MIS denominator pL + p.
             if (pendBsdf) {
-                float pL = 0.0f;
-                if (hit.id > np && hit.id != vId) {
-                    const int si = hit.id - 1 - np;
-                    if (lds.material[hit.id - 1].isLight) {
-                        const DSphereCold& lc = lds.sphereCold[si];
-                        pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));
-                    }
+                if (hit.id > np && hit.id != vId && lds.material[hit.id - 1].isLight) {
+                    const DSphereCold& lc = lds.sphereCold[hit.id - 1 - np];
+#if KAJO_STRICT
+                    const float pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));
+#else
+                    const float pL = lightPdf(lc, vP);
+#endif
+                    const F3 wb = (krcp(pL + pendP) * pendF) * pendCos;
+                    T = pendT * (vS * wb);
                 }
-                F3 wb = (krcp(pL + pendP) * pendF) * pendCos;
-                T = T * (vS * wb);
                 collectEmission = false; // SampleNonEmissiveObjects
                 pendBsdf = false;
             }
@@ -658,6 +755,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 } else {
                     float pt;
                     const bool transparent = flipCoin(rng, m.pT, pt); // Shader.cpp:130-134
+                    KAJO_PROF(3, transparent);
+                    KAJO_PROF(4, !transparent);
                     if (transparent) { // Shader.cpp:137-151; the BSDF colour is the SPECULAR colour
                         F3 nd = transmissionDirection(view, vN, m.ior);
                         float cosA = __builtin_fabsf(dot(nd, vN));
@@ -692,6 +791,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             sampleNext = true;
         }
 
+        KAJO_STAMP(2); // vertex / shadow-result block
+        KAJO_PROF(5, sampleNext);
         if (sampleNext) {
             // ---- sampleLights (Shader.cpp:50-86), one light per trip ------------------------------
             bool shadowRay = false;
@@ -704,6 +805,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 const DSphereCold& lc = lds.sphereCold[si];
                 float pl;
                 const F3 l = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
+#if !KAJO_STRICT
+                pl = lightPdf(lc, vP);
+#endif
                 // The reference traces first and asks the BSDF afterwards; a zero BSDF pdf (always for
                 // the reflector, outside the lobe for Phong) discards the sample either way, so the
                 // trace is skipped for it.
@@ -720,6 +824,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 shadowRay = true;
                 break;
             }
+            KAJO_PROF(7, !shadowRay);
             if (!shadowRay) {
                 // ---- BSDF sampling (Shader.cpp:191-200) ------------------------------------------
                 F3 tg = f3(0.0f, 0.0f, 0.0f), bn = tg;
@@ -742,6 +847,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     pendCos = fmaxf(0.0f, dot(vN, nd));
                     pendP = p;
                     pendBsdf = true;
+                    pendT = T;
+                    T = T * (vS * ((krcp(0.0f + p) * pendF) * pendCos));
                     O = vP + nd * kEps;
                     d = nd;
                     depth++;
@@ -750,6 +857,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             }
         }
 
+        KAJO_STAMP(3); // light loop + BSDF sampling block
         if (pathDone) {
             radiance = radiance + L; // Renderer.cpp:66
             mode = MODE_NEW;
@@ -762,6 +870,12 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     if (counting && lane == 0) {
         atomicAdd(&args.counters[0], ctrTraversals);
         atomicAdd(&args.counters[2], ctrSlots);
+#ifdef KAJO_PROFILE
+        for (int k = 0; k < 16; k++)
+            atomicAdd(&args.counters[4 + k], prof[k]);
+        for (int k = 0; k < 5; k++)
+            atomicAdd(&args.counters[20 + k], stampSum[k]);
+#endif
     }
     if (counting) {
         // vertices are per lane: reduce over the wave first

@@ -176,6 +176,8 @@ void stageScene(const KajoScene& s, StagedScene& out)
         out.invDet.push_back(det);
         out.planeRow.push_back(DFloat4{inv.e(0, 1), inv.e(1, 1), inv.e(2, 1), inv.e(3, 1)});
         out.planeDet.push_back(det);
+        if (det != 1.f)
+            out.planesRigid = 0;
         // Raytracer.cpp:91-93: normal = mat3(M) * -(0,1,0); tangent = mat3(M) * (1,0,0); binormal = n x t
         float n[3], t[3];
         for (int r = 0; r < 3; r++) {
@@ -212,6 +214,8 @@ void stageScene(const KajoScene& s, StagedScene& out)
                 cold.m[3 * r + k] = M.e(k, r);
         const bool translated = isPureTranslation(M) && det == 1.f && isPureTranslation(inv);
         cold.general = !translated;
+        cold.invRadius = 1.f / radius;
+        cold.invTwoPiR2 = 1.f / (6.28318530717958647692f * r2);
         uint32_t off = (uint32_t)out.sphereHot.size();
         if (translated) {
             // inverse is translate(-c) exactly: object-space origin = O + inv[3] = O - c

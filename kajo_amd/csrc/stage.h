@@ -12,7 +12,7 @@ namespace kajo
 
 struct StagedScene
 {
-    int nPlanes = 0, nSpheres = 0, allTranslated = 1;
+    int nPlanes = 0, nSpheres = 0, allTranslated = 1, planesRigid = 1;
     float background[3] = {0, 0, 0};
     float p1[3], p2[3], p3[3], origin[3]; // Renderer.cpp:30-34
     std::vector<DFloat4> planeRow;

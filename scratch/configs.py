@@ -1,0 +1,27 @@
+"""Throughput of the BASELINE.json configs other than the bench's (parity-test cases, not bench lines)."""
+import sys, os, json, time
+ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0,ROOT); sys.path.insert(0,os.path.join(ROOT,'tests'))
+import numpy as np, warnings
+warnings.filterwarnings('ignore')
+from kajo_amd.renderer import HipRenderer
+from kajo_amd.scene import Scene, caustics_scene, stress_scene
+z=np.load(os.path.join(ROOT,'tests/golden/scenes.npz'))
+a1=Scene.from_npz(z,'spheres_a1/','spheres a1'); a169=Scene.from_npz(z,'spheres_a169/','spheres 16:9')
+caus=Scene.from_npz(z,'caustics_a169/','caustics (3 lights)')
+cases=[('C1 256x256 S=16 depth1 1 pass',a1,256,256,16,1,1),
+       ('C2 1080p 16xS32',a169,1920,1080,32,16,8),
+       ('C3/GPU: 4K 16xS32 (1 GPU, 512 of 2048 spp)',a169,3840,2160,32,16,8),
+       ('C4 caustics 1080p 16xS32 (of 128) depth 8',caus,1920,1080,32,16,8),
+       ('C5 1000 spheres/16 lights 4K 1xS32 (of 32)',stress_scene(a169,1000,16),3840,2160,32,1,8),
+       ('C5 at 1080p 1xS32',stress_scene(a169,1000,16),1920,1080,32,1,8)]
+sel=sys.argv[1:] 
+for name,sc,W,H,S,passes,depth in cases:
+    if sel and not any(s in name for s in sel): continue
+    with HipRenderer(sc,W,H,spp=S,depth_limit=depth,counters=True) as r:
+        r.render(passes).wait()          # warm
+        c0=r.counters(); t=time.perf_counter(); r.render(passes).wait(); dt=time.perf_counter()-t; c1=r.counters()
+    paths=c1['paths']-c0['paths']; ms=c1['kernelMs']-c0['kernelMs']
+    print('%-48s %8.1f Mpaths/s wall, kernel %8.2f ms, %5.2f trav/path, %5.2f vert/path, lane eff %.3f, %.2f Gtests/s'%(
+        name, paths/dt/1e6, ms, (c1['traversals']-c0['traversals'])/paths, (c1['vertices']-c0['vertices'])/paths,
+        (c1['traversals']-c0['traversals'])/max(1,(c1['laneSlots']-c0['laneSlots'])), (c1['primitiveTests']-c0['primitiveTests'])/ms/1e6), flush=True)

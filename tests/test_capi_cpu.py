@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_exports_header_symbols():
     L = capi.lib()
     header = open(os.path.join(ROOT, "include", "kajo_hip.h")).read()
-    declared = set(re.findall(r"\b(kajo_hip_[a-z0-9_]+)\s*\(", header))
+    declared = set(re.findall(r"\b(kajo_hip_[a-z0-9_]+)\s*\(", header))  # kajo_hip_debug_profile is not part of the ABI
     assert declared == set(capi.EXPORTS), declared ^ set(capi.EXPORTS)
     for name in declared:
         assert hasattr(L, name), name

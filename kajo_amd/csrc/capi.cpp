@@ -310,7 +310,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     // LDS budget per workgroup (device_scene.h / integrator.inc.hip renderBody): hot records always,
     // cold records too while the total stays small enough for four workgroups per CU (160 KiB / 4).
     const size_t hotBytes = (size_t)v.nPlanes * (16 + 4) + (size_t)v.nSphereHot * 16 + (size_t)v.nSpheres * 4;
-    const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * 80 +
+    const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * sizeof(DMaterial) +
                              (size_t)v.nLights * 4;
     h->coldInLds = hotBytes + coldBytes <= 40 * 1024;
     h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0);

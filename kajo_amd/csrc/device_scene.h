@@ -29,7 +29,7 @@ struct DFloat4
     float x, y, z, w;
 };
 
-struct DMaterial // 20 floats
+struct DMaterial // 24 floats
 {
     float diffuse[3];
     float pRR;      // max over rgb of max(diffuse, specular, transparency)   (Shader.cpp:124-125)
@@ -41,7 +41,14 @@ struct DMaterial // 20 floats
     float exponent;
     float ior;
     uint32_t isLight; // emission != vec4(0)                                  (Shader.cpp:57)
-    float pad[2];
+    // FAST numerics only: the path-weight scales of Shader.cpp:146-147,160-177, which depend only on
+    // the material and on which way the coins fell
+    float sTransparent; // 1 / (pRR * pT)
+    float sDiffuse;     // 1 / (pRR * (1 - pT) * pD)
+    float sSpecular;    // 1 / (pRR * (1 - pT) * (1 - pD))
+    float sStop;        // 1 / (1 - pRR): Russian roulette said stop
+    float sDepth;       // 1 / pRR: depth limit reached
+    float pad;
 };
 
 struct DSphereCold // 16 floats
@@ -68,7 +75,7 @@ struct DSceneView // device pointers + counts, passed to the kernels by value
     const int32_t* light;       // [nLights] sphere indices, scene order
     int32_t nPlanes, nSpheres, nSphereHot, nLights;
     int32_t allTranslated;      // every sphere uses the 1-float4 record
-    int32_t planesRigid;        // every plane has determinant exactly 1
+    int32_t planesRigid;        // every plane has |determinant - 1| <= 2^-20 (FAST numerics only)
     float background[3];
     // camera (Renderer.cpp:29-34): p1, p2 - p1, p3 - p1, origin
     float p1[3], dp2[3], dp3[3], origin[3];

@@ -164,7 +164,8 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     const int np = sc.nPlanes;
 #if !KAJO_STRICT
     if (sc.planesRigid) {
-        // det == 1 for every plane: t * det == t and the second sign test repeats the first
+        // |det - 1| <= 2^-20 for every plane: t * det is t to within its own rounding, and the
+        // second sign test repeats the first
         for (int i = 0; i < np; i++) {
             const DFloat4 r = lds.planeRow[i];
             float denom = r.x * d.x + r.y * d.y + r.z * d.z;
@@ -522,7 +523,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
     // layout: [planeRow np x16][sphereHot nHot x16]{[planeFrame 3np x16][sphereCold ns x64]
-    //         [material (np+ns) x80]}[planeDet np x4][sphereHotOffset ns x4]{[light nL x4]}
+    //         [material (np+ns) x96]}[planeDet np x4][sphereHotOffset ns x4]{[light nL x4]}
     DFloat4* ldsPlaneRow = reinterpret_cast<DFloat4*>(ldsRaw);
     DFloat4* ldsSphereHot = ldsPlaneRow + np;
     DFloat4* cursor = ldsSphereHot + sc.nSphereHot;
@@ -535,10 +536,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         DFloat4* f = cursor;
         DFloat4* c = f + 3 * np;
         DFloat4* m = c + 4 * ns;
-        cursor = m + 5 * (np + ns);
+        cursor = m + 6 * (np + ns);
         stage16(f, sc.planeFrame, 3 * np);
         stage16(c, sc.sphereCold, 4 * ns);
-        stage16(m, sc.material, 5 * (np + ns));
+        stage16(m, sc.material, 6 * (np + ns));
         lds.planeFrame = f;
         lds.sphereCold = reinterpret_cast<const DSphereCold*>(c);
         lds.material = reinterpret_cast<const DMaterial*>(m);
@@ -750,7 +751,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 float pc;
                 const bool cont = flipCoin(rng, m.pRR, pc); // Shader.cpp:124-125
                 if (!cont || depth >= args.depthLimit) {
+#if KAJO_STRICT
                     L = L + T * (krcp(pc) * vE); // Shader.cpp:126-127
+#else
+                    L = L + T * ((cont ? m.sDepth : m.sStop) * vE);
+#endif
                     pathDone = true;
                 } else {
                     float pt;
@@ -762,7 +767,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         float cosA = __builtin_fabsf(dot(nd, vN));
                         F3 spec = ld3(m.specular);
                         F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
+#if KAJO_STRICT
                         F3 w = (kdiv(krcp(pc) * 1.0f, pt) * f) * __builtin_fabsf(dot(vN, nd));
+#else
+                        F3 w = (m.sTransparent * f) * __builtin_fabsf(dot(vN, nd));
+#endif
                         L = L + T * (w * vE);
                         T = T * w;
                         O = vP + nd * kEps;
@@ -775,7 +784,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         vKind = diffuse ? 0 : (m.exponent != 0.0f ? 1 : 2);
                         vColor = diffuse ? ld3(m.diffuse) : ld3(m.specular);
                         vExp = m.exponent;
+#if KAJO_STRICT
                         vS = kdiv(kdiv(krcp(pc) * 1.0f, pt) * 1.0f, pd); // 1/pc * 1/pt * 1/pd
+#else
+                        vS = diffuse ? m.sDiffuse : m.sSpecular;
+#endif
                         vR = reflect(view, vN);
                         vLd = f3(0.0f, 0.0f, 0.0f);
                         lightK = 0;

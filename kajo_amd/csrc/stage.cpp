@@ -155,6 +155,11 @@ DMaterial stageMaterial(const KajoMaterial& k)
     d.exponent = k.specularExponent;
     d.ior = k.refractiveIndex;
     d.isLight = !(k.emission[0] == 0 && k.emission[1] == 0 && k.emission[2] == 0 && k.emission[3] == 0);
+    d.sTransparent = 1.f / d.pRR * 1.f / d.pT;
+    d.sDiffuse = 1.f / d.pRR * 1.f / (1.f - d.pT) * 1.f / d.pD;
+    d.sSpecular = 1.f / d.pRR * 1.f / (1.f - d.pT) * 1.f / (1.f - d.pD);
+    d.sStop = 1.f / (1.f - d.pRR);
+    d.sDepth = 1.f / d.pRR;
     return d;
 }
 
@@ -176,7 +181,9 @@ void stageScene(const KajoScene& s, StagedScene& out)
         out.invDet.push_back(det);
         out.planeRow.push_back(DFloat4{inv.e(0, 1), inv.e(1, 1), inv.e(2, 1), inv.e(3, 1)});
         out.planeDet.push_back(det);
-        if (det != 1.f)
+        // FAST numerics drop the "* determinant" of Raytracer.cpp:97 when every plane is rigid to
+        // within float rounding of a rotation matrix (|det - 1| <= 2^-20; spheres.json: 0.9999997)
+        if (!(std::fabs(det - 1.f) <= 9.5367431640625e-7f))
             out.planesRigid = 0;
         // Raytracer.cpp:91-93: normal = mat3(M) * -(0,1,0); tangent = mat3(M) * (1,0,0); binormal = n x t
         float n[3], t[3];

@@ -56,6 +56,7 @@ extern "C" {
 /* KajoParams.flags */
 #define KAJO_FLAG_STRICT 1u   /* strict numerics: bit-identical to the CPU oracle (slower) */
 #define KAJO_FLAG_COUNTERS 2u /* maintain device-side work counters */
+#define KAJO_FLAG_NO_GRID 4u  /* always walk every sphere (no uniform grid for large scenes) */
 
 typedef struct KajoParams {
     int32_t samplesPerPass; /* S: nominal samples per pixel per pass (reference: 32, Renderer.cpp:21);
@@ -75,7 +76,8 @@ typedef struct KajoCounters {
     uint64_t paths;          /* camera paths traced = pixels * n^2 * passes */
     uint64_t traversals;     /* closest-hit scene walks (device counter; 0 without KAJO_FLAG_COUNTERS) */
     uint64_t vertices;       /* shaded path vertices (device counter) */
-    uint64_t primitiveTests; /* traversals * (nPlanes + nSpheres) */
+    uint64_t primitiveTests; /* traversals * (nPlanes + nSpheres): what walking every object costs; with
+                                the uniform grid of large scenes the spheres actually tested are fewer */
     uint64_t laneSlots;      /* 64 * wave-iterations of the trace loop: traversals / laneSlots = lane efficiency */
     double kernelMs;         /* summed device time of the render kernels (HIP events on the handle's stream) */
     uint64_t launches;       /* render kernel launches */

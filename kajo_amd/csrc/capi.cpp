@@ -283,7 +283,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     h->ownStream = true;
 
     // ---- scene -----------------------------------------------------------------------------
-    kajo::stageScene(*scene, h->staged);
+    kajo::stageScene(*scene, h->staged, (p.flags & KAJO_FLAG_NO_GRID) ? 0 : 48);
     const kajo::StagedScene& st = h->staged;
     DSceneView& v = h->view;
     CREATE_TRY(upload(st.planeRow, &v.planeRow, h->sceneBuffers));
@@ -294,6 +294,22 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     CREATE_TRY(upload(st.sphereCold, &v.sphereCold, h->sceneBuffers));
     CREATE_TRY(upload(st.material, &v.material, h->sceneBuffers));
     CREATE_TRY(upload(st.light, &v.light, h->sceneBuffers));
+    {
+        const uint32_t* cellStart = nullptr;
+        const uint32_t* items = nullptr;
+        CREATE_TRY(upload(st.gridCellStart, &cellStart, h->sceneBuffers));
+        CREATE_TRY(upload(st.gridItems, &items, h->sceneBuffers));
+        v.grid.enabled = st.gridEnabled;
+        v.grid.cellStart = cellStart;
+        v.grid.items = items;
+        for (int k = 0; k < 3; k++) {
+            v.grid.dim[k] = st.gridDim[k];
+            v.grid.bmin[k] = st.gridEnabled ? st.gridMin[k] : 0.f;
+            v.grid.bmax[k] = st.gridEnabled ? st.gridMax[k] : 0.f;
+            v.grid.cell[k] = st.gridEnabled ? st.gridCell[k] : 1.f;
+            v.grid.invCell[k] = st.gridEnabled ? 1.f / st.gridCell[k] : 1.f;
+        }
+    }
     v.nPlanes = st.nPlanes;
     v.nSpheres = st.nSpheres;
     v.nSphereHot = (int)st.sphereHot.size();
@@ -312,7 +328,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     const size_t hotBytes = (size_t)v.nPlanes * (16 + 4) + (size_t)v.nSphereHot * 16 + (size_t)v.nSpheres * 4;
     const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * sizeof(DMaterial) +
                              (size_t)v.nLights * 4;
-    h->coldInLds = hotBytes + coldBytes <= 40 * 1024;
+    h->coldInLds = hotBytes + coldBytes <= 40 * 1024 && !st.gridEnabled;
     h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0);
     if (h->ldsBytes > 160 * 1024) {
         destroy(h);

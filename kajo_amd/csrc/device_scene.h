@@ -63,6 +63,20 @@ struct DSphereCold // 16 floats
 // sphereHotOffset[i]: index of the sphere's first float4 in the hot array; bit 31 set = general
 #define KAJO_SPHERE_GENERAL 0x80000000u
 
+// Uniform grid over the spheres (large scenes): a conservative culling structure. A ray visits the
+// cells it crosses front to back (3D-DDA) and runs the SAME per-sphere intersection arithmetic on
+// the spheres registered in each cell; the closest hit, and the "later object wins" tie rule of
+// Raytracer.cpp:108-124, are those of the brute-force walk. Planes are always tested one by one.
+struct DGrid
+{
+    int32_t enabled;
+    int32_t dim[3];
+    float bmin[3], bmax[3];
+    float cell[3], invCell[3];
+    const uint32_t* cellStart; // [dim.x * dim.y * dim.z + 1]
+    const uint32_t* items;     // sphere indices, ascending within a cell
+};
+
 struct DSceneView // device pointers + counts, passed to the kernels by value
 {
     const DFloat4* planeRow;    // [nPlanes]
@@ -77,6 +91,7 @@ struct DSceneView // device pointers + counts, passed to the kernels by value
     int32_t allTranslated;      // every sphere uses the 1-float4 record
     int32_t planesRigid;        // every plane has |determinant - 1| <= 2^-20 (FAST numerics only)
     float background[3];
+    DGrid grid;
     // camera (Renderer.cpp:29-34): p1, p2 - p1, p3 - p1, origin
     float p1[3], dp2[3], dp3[3], origin[3];
 };

@@ -155,6 +155,135 @@ struct LdsScene
     const int32_t* light;
 };
 
+// One sphere of Raytracer.cpp:21-72 up to (not including) processIntersection: returns false when the
+// reference returns early (discriminant < 0, or both roots behind the origin); otherwise th = the
+// object-space parameter the reference reports and ts = th * determinant.
+KDEV bool sphereCandidate(const DSceneView& sc, const LdsScene& lds, int i, F3 O, F3 d, float aT, float iaT, float& ts, float& th)
+{
+    // a t^2 + 2 h t + c = 0 in object space (the reference's b = 2 h); ia = 1 / a
+    float a, h, c, det;
+#if !KAJO_STRICT
+    float ia;
+#endif
+    const uint32_t off = sc.allTranslated ? (uint32_t)i : lds.sphereHotOffset[i];
+    if (!(off & KAJO_SPHERE_GENERAL)) {
+        const DFloat4 s = lds.sphereHot[off];
+        F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+        a = aT;
+        h = dot(d, o);
+        c = dot(o, o) - s.w;
+        det = 1.0f;
+#if !KAJO_STRICT
+        ia = iaT;
+#endif
+    } else {
+        const int k = (int)(off & ~KAJO_SPHERE_GENERAL);
+        const DFloat4 r0 = lds.sphereHot[k], r1 = lds.sphereHot[k + 1], r2 = lds.sphereHot[k + 2];
+        const DFloat4 q = lds.sphereHot[k + 3];
+        F3 dir = f3(r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z,
+                    r2.x * d.x + r2.y * d.y + r2.z * d.z);
+        F3 o = f3(r0.x * O.x + r0.y * O.y + r0.z * O.z + r0.w * 1.0f, r1.x * O.x + r1.y * O.y + r1.z * O.z + r1.w * 1.0f,
+                  r2.x * O.x + r2.y * O.y + r2.z * O.z + r2.w * 1.0f);
+        a = dot(dir, dir);
+        h = dot(dir, o);
+        c = dot(o, o) - q.x;
+        det = q.y;
+#if !KAJO_STRICT
+        ia = krcp(a);
+#endif
+    }
+#if KAJO_STRICT
+    // Raytracer.cpp:26-44 verbatim: b = 2 dot, discriminant b^2 - 4ac, q by the sign of b,
+    // roots q/a and c/q, sorted
+    float b = 2 * h;
+    float discr = b * b - 4 * a * c;
+    float sq = ksqrt(discr);
+    float q = (b < 0.0f) ? (-b - sq) * .5f : (-b + sq) * .5f;
+    float t0 = kdiv(q, a);
+    float t1 = kdiv(c, q);
+    bool sw = t0 > t1;
+    float lo = sw ? t1 : t0, hi = sw ? t0 : t1;
+#else
+    // The same two roots (q/a and c/q are the roots of a t^2 + b t + c, by Vieta) as
+    // t = (-h -+ sqrt(h^2 - a c)) / a: one reciprocal per ray instead of two per sphere, no
+    // sort. Differs from the reference's evaluation in the last bits only.
+    float discr = h * h - a * c;
+    float sq = ksqrt(discr);
+    float lo = (-h - sq) * ia, hi = (sq - h) * ia;
+#endif
+    th = (lo < 0.0f) ? hi : lo;
+    ts = th * det;
+    return !(discr < 0.0f) && !(hi < 0.0f);
+}
+
+// Large scenes: visit only the spheres registered in the grid cells the ray crosses, front to back.
+// Acceptance reproduces the brute-force walk: closest ts wins; among equal ts the later object wins
+// (Raytracer.cpp:115 rejects only ts > max), so a sphere ties over a plane and over a lower-index sphere.
+KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float aT, float iaT, float& tMax, int& best, float& bestT0)
+{
+    const DGrid& g = sc.grid;
+    const int np = sc.nPlanes;
+    const float inf = __builtin_inff();
+    const float ix_ = 1.0f / d.x, iy_ = 1.0f / d.y, iz_ = 1.0f / d.z;
+    // slab test against the grid bounds (fminf/fmaxf drop the NaN of 0 * inf)
+    float ax = (g.bmin[0] - O.x) * ix_, bx = (g.bmax[0] - O.x) * ix_;
+    float ay = (g.bmin[1] - O.y) * iy_, by = (g.bmax[1] - O.y) * iy_;
+    float az = (g.bmin[2] - O.z) * iz_, bz = (g.bmax[2] - O.z) * iz_;
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    // a ray parallel to a slab and outside it never enters
+    bool outside = (d.x == 0.0f && (O.x < g.bmin[0] || O.x > g.bmax[0])) || (d.y == 0.0f && (O.y < g.bmin[1] || O.y > g.bmax[1])) ||
+                   (d.z == 0.0f && (O.z < g.bmin[2] || O.z > g.bmax[2]));
+    if (outside || !(tn <= tf) || !(tn <= tMax))
+        return;
+    const float px = O.x + d.x * tn, py = O.y + d.y * tn, pz = O.z + d.z * tn;
+    int cx = min(max((int)__builtin_floorf((px - g.bmin[0]) * g.invCell[0]), 0), g.dim[0] - 1);
+    int cy = min(max((int)__builtin_floorf((py - g.bmin[1]) * g.invCell[1]), 0), g.dim[1] - 1);
+    int cz = min(max((int)__builtin_floorf((pz - g.bmin[2]) * g.invCell[2]), 0), g.dim[2] - 1);
+    const int sx = d.x >= 0.0f ? 1 : -1, sy = d.y >= 0.0f ? 1 : -1, sz = d.z >= 0.0f ? 1 : -1;
+    // ray parameter at which the next cell boundary along each axis is crossed, and its increment
+    float nx = d.x == 0.0f ? inf : ((cx + (sx > 0 ? 1 : 0)) * g.cell[0] + g.bmin[0] - O.x) * ix_;
+    float ny = d.y == 0.0f ? inf : ((cy + (sy > 0 ? 1 : 0)) * g.cell[1] + g.bmin[1] - O.y) * iy_;
+    float nz = d.z == 0.0f ? inf : ((cz + (sz > 0 ? 1 : 0)) * g.cell[2] + g.bmin[2] - O.z) * iz_;
+    const float dx = d.x == 0.0f ? inf : g.cell[0] * __builtin_fabsf(ix_);
+    const float dy = d.y == 0.0f ? inf : g.cell[1] * __builtin_fabsf(iy_);
+    const float dz = d.z == 0.0f ? inf : g.cell[2] * __builtin_fabsf(iz_);
+    for (int guard = g.dim[0] + g.dim[1] + g.dim[2] + 3; guard > 0; guard--) {
+        const int cell = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+        const uint32_t e = g.cellStart[cell + 1];
+        for (uint32_t k = g.cellStart[cell]; k < e; k++) {
+            const int i = (int)g.items[k];
+            float ts, th;
+            const bool valid = sphereCandidate(sc, lds, i, O, d, aT, iaT, ts, th);
+            const int id = np + 1 + i;
+            const bool ok = valid && !(ts < 0.0f) && (ts < tMax || (ts == tMax && id > best));
+            tMax = ok ? ts : tMax;
+            best = ok ? id : best;
+            bestT0 = ok ? th : bestT0;
+        }
+        const float tExit = fminf(nx, fminf(ny, nz));
+        if (tMax < tExit) // nothing in a later cell can be closer (spheres are registered with a margin)
+            break;
+        if (nx <= ny && nx <= nz) {
+            cx += sx;
+            nx += dx;
+            if (cx < 0 || cx >= g.dim[0])
+                break;
+        } else if (ny <= nz) {
+            cy += sy;
+            ny += dy;
+            if (cy < 0 || cy >= g.dim[1])
+                break;
+        } else {
+            cz += sz;
+            nz += dz;
+            if (cz < 0 || cz >= g.dim[2])
+                break;
+        }
+    }
+}
+
+template <bool GRID>
 KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
 {
     float tMax = __builtin_inff(); // Ray.cpp:10-13; minDistance = 0
@@ -193,6 +322,14 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     const float aT = dot(d, d); // a of every translated sphere (mat3(inverse) = identity)
 #if !KAJO_STRICT
     const float iaT = krcp(aT);
+#else
+    const float iaT = 0.0f;
+#endif
+    if (GRID && sc.grid.enabled) {
+        gridWalk(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
+        return Hit{best, tMax, bestT0};
+    }
+#if !KAJO_STRICT
     if (sc.allTranslated) {
         // every sphere is (centre, radius): a = d.d is one value per ray; the two roots are
         // (-h -+ sqrt(h^2 - a c)) / a
@@ -214,59 +351,8 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     }
 #endif
     for (int i = 0; i < ns; i++) { // Raytracer.cpp:21-72
-        // a t^2 + 2 h t + c = 0 in object space (the reference's b = 2 h); ia = 1 / a
-        float a, h, c, det;
-#if !KAJO_STRICT
-        float ia;
-#endif
-        if (sc.allTranslated || !(lds.sphereHotOffset[i] & KAJO_SPHERE_GENERAL)) {
-            const DFloat4 s = lds.sphereHot[sc.allTranslated ? i : (int)lds.sphereHotOffset[i]];
-            F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
-            a = aT;
-            h = dot(d, o);
-            c = dot(o, o) - s.w;
-            det = 1.0f;
-#if !KAJO_STRICT
-            ia = iaT;
-#endif
-        } else {
-            const int k = (int)(lds.sphereHotOffset[i] & ~KAJO_SPHERE_GENERAL);
-            const DFloat4 r0 = lds.sphereHot[k], r1 = lds.sphereHot[k + 1], r2 = lds.sphereHot[k + 2];
-            const DFloat4 q = lds.sphereHot[k + 3];
-            F3 dir = f3(r0.x * d.x + r0.y * d.y + r0.z * d.z, r1.x * d.x + r1.y * d.y + r1.z * d.z,
-                        r2.x * d.x + r2.y * d.y + r2.z * d.z);
-            F3 o = f3(r0.x * O.x + r0.y * O.y + r0.z * O.z + r0.w * 1.0f, r1.x * O.x + r1.y * O.y + r1.z * O.z + r1.w * 1.0f,
-                      r2.x * O.x + r2.y * O.y + r2.z * O.z + r2.w * 1.0f);
-            a = dot(dir, dir);
-            h = dot(dir, o);
-            c = dot(o, o) - q.x;
-            det = q.y;
-#if !KAJO_STRICT
-            ia = krcp(a);
-#endif
-        }
-#if KAJO_STRICT
-        // Raytracer.cpp:26-44 verbatim: b = 2 dot, discriminant b^2 - 4ac, q by the sign of b,
-        // roots q/a and c/q, sorted
-        float b = 2 * h;
-        float discr = b * b - 4 * a * c;
-        float sq = ksqrt(discr);
-        float q = (b < 0.0f) ? (-b - sq) * .5f : (-b + sq) * .5f;
-        float t0 = kdiv(q, a);
-        float t1 = kdiv(c, q);
-        bool sw = t0 > t1;
-        float lo = sw ? t1 : t0, hi = sw ? t0 : t1;
-#else
-        // The same two roots (q/a and c/q are the roots of a t^2 + b t + c, by Vieta) as
-        // t = (-h -+ sqrt(h^2 - a c)) / a: one reciprocal per ray instead of two per sphere, no
-        // sort. Differs from the reference's evaluation in the last bits only.
-        float discr = h * h - a * c;
-        float sq = ksqrt(discr);
-        float lo = (-h - sq) * ia, hi = (sq - h) * ia;
-#endif
-        float th = (lo < 0.0f) ? hi : lo;
-        float ts = th * det;
-        bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(ts > tMax || ts < 0.0f);
+        float ts, th;
+        bool ok = sphereCandidate(sc, lds, i, O, d, aT, iaT, ts, th) && !(ts > tMax || ts < 0.0f);
         tMax = ok ? ts : tMax;
         best = ok ? np + 1 + i : best;
         bestT0 = ok ? th : bestT0;
@@ -512,9 +598,9 @@ KDEV void stage16(DFloat4* dst, const void* src, int count)
         dst[i] = s[i];
 }
 
-// COLD_LDS: shading frames, sphere centres, materials and the light list are staged into LDS
-// next to the hot records (scenes up to a few hundred objects); otherwise they are read from
-// global memory.
+// COLD_LDS (small scenes): shading frames, sphere centres, materials and the light list are staged
+// into LDS next to the hot records and every sphere is tested. !COLD_LDS (large scenes): the cold
+// records are read from global memory (L2) and the spheres are reached through the uniform grid.
 template <bool COLD_LDS>
 KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 {
@@ -705,7 +791,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
         KAJO_STAMP(0); // camera-ray block
         // ---- one ray per lane through the whole scene ------------------------------------------
-        const Hit hit = trace(sc, lds, O, d);
+        const Hit hit = trace<!COLD_LDS>(sc, lds, O, d);
         KAJO_STAMP(1); // traversal
         if (counting) {
             ctrTraversals += __builtin_popcountll(activeMask);

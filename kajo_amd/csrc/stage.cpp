@@ -12,6 +12,7 @@
 #include "stage.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace kajo
@@ -163,9 +164,94 @@ DMaterial stageMaterial(const KajoMaterial& k)
     return d;
 }
 
+// World-space bounding box of sphere i: the unit-radius-r sphere under M is an ellipsoid whose
+// half-extent along world axis k is r * |row k of mat3(M)|.
+void sphereBounds(const KajoSphere& sp, float lo[3], float hi[3])
+{
+    const Mat4 M = load(sp.transform);
+    for (int k = 0; k < 3; k++) {
+        const double e = (double)sp.radius * std::sqrt((double)M.e(0, k) * M.e(0, k) + (double)M.e(1, k) * M.e(1, k) +
+                                                        (double)M.e(2, k) * M.e(2, k));
+        const double c = M.e(3, k);
+        const double pad = 1e-4 * (e + std::fabs(c)) + 1e-5; // registration margin >> float rounding of the DDA
+        lo[k] = (float)(c - e - pad);
+        hi[k] = (float)(c + e + pad);
+    }
+}
+
+void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
+{
+    out.gridEnabled = false;
+    const int n = s.nSpheres;
+    if (n < gridMinSpheres || gridMinSpheres <= 0)
+        return;
+    std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
+    float bmin[3] = {3e38f, 3e38f, 3e38f}, bmax[3] = {-3e38f, -3e38f, -3e38f};
+    for (int i = 0; i < n; i++) {
+        sphereBounds(s.spheres[i], &lo[3 * i], &hi[3 * i]);
+        for (int k = 0; k < 3; k++) {
+            if (!(lo[3 * i + k] > -3e37f && hi[3 * i + k] < 3e37f))
+                return; // non-finite geometry: keep the brute-force walk
+            bmin[k] = std::fmin(bmin[k], lo[3 * i + k]);
+            bmax[k] = std::fmax(bmax[k], hi[3 * i + k]);
+        }
+    }
+    // about four cells per sphere, cells as cubic as the bounds allow, at most 128 per axis
+    double ext[3], vol = 1;
+    for (int k = 0; k < 3; k++) {
+        ext[k] = std::fmax((double)bmax[k] - bmin[k], 1e-3);
+        vol *= ext[k];
+    }
+    double cellsPerSphere = 4.0;
+    if (const char* e = std::getenv("KAJO_GRID_CELLS_PER_SPHERE")) // tuning knob
+        cellsPerSphere = std::atof(e) > 0 ? std::atof(e) : cellsPerSphere;
+    const double side = std::cbrt(vol / (cellsPerSphere * n));
+    size_t cells = 1;
+    for (int k = 0; k < 3; k++) {
+        int d = (int)std::ceil(ext[k] / side);
+        d = d < 1 ? 1 : (d > 128 ? 128 : d);
+        out.gridDim[k] = d;
+        out.gridMin[k] = bmin[k];
+        out.gridMax[k] = bmax[k];
+        out.gridCell[k] = (float)(ext[k] / d);
+        cells *= (size_t)d;
+    }
+    auto cellRange = [&](int i, int k, int& a, int& b) {
+        a = (int)std::floor((lo[3 * i + k] - bmin[k]) / out.gridCell[k]);
+        b = (int)std::floor((hi[3 * i + k] - bmin[k]) / out.gridCell[k]);
+        a = a < 0 ? 0 : (a >= out.gridDim[k] ? out.gridDim[k] - 1 : a);
+        b = b < 0 ? 0 : (b >= out.gridDim[k] ? out.gridDim[k] - 1 : b);
+    };
+    std::vector<uint32_t> count(cells + 1, 0);
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = 0; i < n; i++) { // ascending sphere index within every cell
+            int x0, x1, y0, y1, z0, z1;
+            cellRange(i, 0, x0, x1);
+            cellRange(i, 1, y0, y1);
+            cellRange(i, 2, z0, z1);
+            for (int z = z0; z <= z1; z++)
+                for (int y = y0; y <= y1; y++)
+                    for (int x = x0; x <= x1; x++) {
+                        const size_t c = ((size_t)z * out.gridDim[1] + y) * out.gridDim[0] + x;
+                        if (pass == 0)
+                            count[c + 1]++;
+                        else
+                            out.gridItems[count[c]++] = (uint32_t)i;
+                    }
+        }
+        if (pass == 0) {
+            for (size_t c = 0; c < cells; c++)
+                count[c + 1] += count[c];
+            out.gridCellStart = count;
+            out.gridItems.assign(count[cells], 0);
+        }
+    }
+    out.gridEnabled = true;
+}
+
 } // namespace
 
-void stageScene(const KajoScene& s, StagedScene& out)
+void stageScene(const KajoScene& s, StagedScene& out, int gridMinSpheres)
 {
     out = StagedScene();
     out.nPlanes = s.nPlanes;
@@ -241,6 +327,8 @@ void stageScene(const KajoScene& s, StagedScene& out)
         if (m.isLight)
             out.light.push_back(i);
     }
+
+    buildGrid(s, out, gridMinSpheres);
 
     // camera basis, Renderer.cpp:29-34
     const Mat4 view = load(s.camera.transform);

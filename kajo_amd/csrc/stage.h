@@ -24,9 +24,14 @@ struct StagedScene
     std::vector<DMaterial> material;
     std::vector<int32_t> light;
     std::vector<float> invDet; // 17 floats per object, planes first (debug / tests)
+    // uniform grid over the spheres (built when there are at least `gridMinSpheres` of them)
+    bool gridEnabled = false;
+    int gridDim[3] = {0, 0, 0};
+    float gridMin[3], gridMax[3], gridCell[3];
+    std::vector<uint32_t> gridCellStart, gridItems;
 };
 
-void stageScene(const KajoScene& scene, StagedScene& out);
+void stageScene(const KajoScene& scene, StagedScene& out, int gridMinSpheres = 48);
 
 } // namespace kajo
 

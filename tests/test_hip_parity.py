@@ -73,6 +73,27 @@ def test_strict_bit_exact_synthetic_scenes(O, scenes):
         assert (same | nan_both).all(), (sc.name, frame_stats(got[..., :3], want[..., :3]))
 
 
+def test_builtin_test_scene_strict(O):
+    """renderer/Main.cpp:13-95 (the scene the reference builds without a scene file), as produced by the
+    host-side loader: emission alpha 0, transparency (.9,.9,.9,.9), Phong exponent without specular colour."""
+    import os
+    from test_host_parser import LIB, parse
+    if not os.path.exists(LIB):
+        pytest.skip("libkajo_host.so not built")
+    sc = parse(None, 4.0 / 3.0, "buildTestScene")
+    W, H = 64, 48
+    want = O.create(sc, math=1).render(W, H, S=16, passes=2, seed=SEED, depth_limit=8)
+    with HipRenderer(sc, W, H, spp=16, seed=SEED, strict=True) as r:
+        got = r.render(2).radiance()
+    same = got[..., :3].view(np.uint32) == want[..., :3].view(np.uint32)
+    nan_both = np.isnan(got[..., :3]) & np.isnan(want[..., :3])
+    assert (same | nan_both).all(), frame_stats(got[..., :3], want[..., :3])
+    with HipRenderer(sc, W, H, spp=16, seed=SEED) as r:
+        fast = r.render(2).radiance()
+    s = frame_stats(fast[..., :3] / 2, O.create(sc, math=0).render(W, H, S=16, passes=2, seed=SEED)[..., :3] / 2)
+    assert s["median"] <= 1e-5 and s["p99"] <= 2e-3 and s["clamped_rmse"] <= 1e-3, s
+
+
 def test_grid_walk_equals_brute_force(O, scenes):
     """Large scenes reach their spheres through a uniform grid (3D-DDA); the closest hit and the tie rule
     must be those of the walk over every sphere: STRICT grid == oracle (which tests every sphere) bit for

@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B on the GPU box: rebuild the kernels with each KFLAGS variant and run the bench (no CPU legs).
-# usage: scratch/ab.sh "name1|flags1" "name2|flags2" ...
+# usage: tools/ab.sh "name1|flags1" "name2|flags2" ...
 cd "$(dirname "$0")/.."
 for v in "$@"; do
   name="${v%%|*}"; flags="${v#*|}"

@@ -65,6 +65,15 @@ def flops_per_path(n_planes, n_spheres, traversals_per_path, vertices_per_path):
     return traversals_per_path * (14 * n_planes + 28 * n_spheres) + vertices_per_path * 150
 
 
+def measured_traffic(world, strict, W, H):
+    """HBM bytes per launch of the render kernel from the rocprofv3 PMC passes committed under profiles/
+    (bench.py cannot collect counters itself); only for the exact workload they were taken on."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if world != 1 or strict or (W, H) != (1920, 1080) or not os.path.exists(path):
+        return None
+    return json.load(open(path))["traffic_bytes_per_launch"]
+
+
 def cpu_baseline(scene, W, H):
     """The reference's own hot loop (cpu::Renderer::render on row slices, one std::async per core,
     renderer/cpu/Scheduler.cpp:32-42) from the compiled reference when oracle/_ref travelled with the
@@ -214,7 +223,7 @@ def main():
                        "numerics": "strict" if args.strict else "fast", "tiles": "64x16 round-robin over ranks",
                        "paths_per_step": paths_per_step},
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_TFLOPS, "traffic": measured_traffic(world, args.strict, W, H),
                          "kernel": "kajo_render_strict" if args.strict else "kajo_render_fast",
                          "kernel_ms_per_launch": kernel_ms, "launches_per_step": launches / args.steps,
                          "flops_per_path": fpp, "traversals_per_path": trav, "vertices_per_path": vert,

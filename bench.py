@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--strict", action="store_true", help="time the STRICT kernels instead of the product path")
     ap.add_argument("--passes-per-launch", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo: rehearsal of the N > 1 control flow on fewer GPUs than ranks (gather staged through "
+                         "host memory, every rank on GPU LOCAL_RANK %% device_count); the graded runs use nccl = RCCL")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -133,12 +136,17 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the backend has no CPU path")
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from kajo_amd.renderer import HipRenderer
     from kajo_amd.scene import Scene
@@ -165,7 +173,13 @@ def main():
         r.render(PASSES)
         r.wait()
         if world > 1:
-            gather_to_root(dist, mine, gathered, rank, world)
+            if args.backend == "nccl":
+                gather_to_root(dist, mine, gathered, rank, world)
+            else:  # rehearsal: gloo moves host tensors
+                host = torch.empty(world * mine.numel()) if rank == 0 else None
+                gather_to_root(dist, mine.cpu(), host, rank, world)
+                if rank == 0:
+                    gathered.copy_(host)
             if rank == 0:
                 torch.cuda.current_stream().synchronize()
                 r.compose(gathered.data_ptr())
@@ -190,7 +204,7 @@ def main():
     dt = time.perf_counter() - t0
     c1 = r.counters()
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -242,6 +256,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -124,6 +124,20 @@ int kajo_hip_counters(kajo_hip_t h, KajoCounters* out);
    the camera basis p1, p2, p3, origin (Renderer.cpp:30-34), 12 floats. For tests. */
 int kajo_hip_stage_scene(const KajoScene* scene, float* invDet17, float* basis12);
 
+/* Known-answer hooks: run the kernels' OWN device functions on caller-supplied rays, so that the
+   vectors captured from the compiled reference (tests/golden/kat_trace.npz, kat_shade.npz) can be
+   checked on the GPU function by function. All pointers are HOST memory; scenes whose hot records
+   exceed 48 KiB of LDS are refused.
+     kat_trace: closest hit of Raytracer::trace (renderer/cpu/Raytracer.cpp:126-138) per ray: object index
+                (0 = miss, planes 1.., then spheres), ray.maxDistance, position, normal, tangent, binormal.
+     kat_shade: trace + Shader::shade (renderer/cpu/Shader.cpp:113-178) of one path per ray from the given
+                128-bit RNG state (no jitter draw), with the handle's depth limit: RGB and the RNG state
+                afterwards (pins the number of draws). */
+int kajo_hip_kat_trace(kajo_hip_t h, int n, const float* origins, const float* dirs, int32_t* objIndex, float* t,
+                       float* position, float* normal, float* tangent, float* binormal);
+int kajo_hip_kat_shade(kajo_hip_t h, int n, const float* origins, const float* dirs, const uint64_t* states, float* rgb,
+                       uint64_t* finalStates);
+
 const char* kajo_hip_last_error(void);
 const char* kajo_hip_version(void);
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "kajo_hip_default_params", "kajo_hip_create", "kajo_hip_destroy", "kajo_hip_render", "kajo_hip_wait",
     "kajo_hip_reset", "kajo_hip_resolve_argb8", "kajo_hip_read_radiance", "kajo_hip_resolve_argb8_device",
     "kajo_hip_tile_buffer", "kajo_hip_compose", "kajo_hip_set_stream", "kajo_hip_counters",
-    "kajo_hip_stage_scene", "kajo_hip_last_error", "kajo_hip_version",
+    "kajo_hip_stage_scene", "kajo_hip_last_error", "kajo_hip_version", "kajo_hip_kat_trace", "kajo_hip_kat_shade",
 ]
 
 
@@ -85,6 +85,8 @@ def lib():
         L.kajo_hip_counters.argtypes = [C.c_void_p, C.POINTER(KajoCounters)]
         L.kajo_hip_stage_scene.argtypes = [C.POINTER(KajoScene), C.c_void_p, C.c_void_p]
         L.kajo_hip_default_params.argtypes = [C.POINTER(KajoParams)]
+        L.kajo_hip_kat_trace.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
+        L.kajo_hip_kat_shade.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         _lib = L
     return _lib
 

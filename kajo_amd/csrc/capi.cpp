@@ -29,6 +29,10 @@ int kajo_render_strict_set_lds(int coldInLds, size_t lds);
 int kajo_resolve_fast_launch(const void* frame, int count, float passes, void* dst, void* stream);
 int kajo_resolve_strict_launch(const void* frame, int count, float passes, void* dst, void* stream);
 int kajo_compose_launch(const void* gathered, const TileMap* map, void* frame, void* stream);
+int kajo_kat_shade_fast_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
+int kajo_kat_shade_strict_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
+int kajo_kat_trace_fast_launch(const KatTraceArgs*, unsigned grid, size_t lds, void* stream);
+int kajo_kat_trace_strict_launch(const KatTraceArgs*, unsigned grid, size_t lds, void* stream);
 }
 
 namespace
@@ -94,7 +98,7 @@ struct KajoHip
     bool frameValid = false;
     unsigned long long* counters = nullptr; // device [4]
     int passesDone = 0;
-    size_t ldsBytes = 0;
+    size_t ldsBytes = 0, hotBytes = 0;
     int coldInLds = 1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // kernel timing
     std::vector<hipEvent_t> eventPool;
@@ -328,6 +332,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     const size_t hotBytes = (size_t)v.nPlanes * (16 + 4) + (size_t)v.nSphereHot * 16 + (size_t)v.nSpheres * 4;
     const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * sizeof(DMaterial) +
                              (size_t)v.nLights * 4;
+    h->hotBytes = hotBytes;
     h->coldInLds = hotBytes + coldBytes <= 40 * 1024 && !st.gridEnabled;
     h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0);
     if (h->ldsBytes > 160 * 1024) {
@@ -550,6 +555,119 @@ int kajo_hip_read_radiance(kajo_hip_t h, float* dst)
         return rc;
     HIP_TRY(hipMemcpyAsync(dst, h->frame, (size_t)h->W * h->H * 16, hipMemcpyDeviceToHost, h->stream));
     return kajo_hip_wait(h);
+}
+
+namespace
+{
+
+struct DeviceBuffer // scratch for the known-answer entry points
+{
+    void* p = nullptr;
+    ~DeviceBuffer()
+    {
+        if (p)
+            (void)hipFree(p);
+    }
+    hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 1); }
+};
+
+} // namespace
+
+int kajo_hip_kat_trace(kajo_hip_t h, int n, const float* origins, const float* dirs, int32_t* objIndex, float* t,
+                       float* position, float* normal, float* tangent, float* binormal)
+{
+    if (!h || n < 0 || !origins || !dirs || !objIndex || !t || !position || !normal || !tangent || !binormal)
+        return fail(KAJO_E_INVALID, "null argument");
+    if (h->hotBytes > 48 * 1024)
+        return fail(KAJO_E_INVALID, "known-answer entry points are limited to scenes whose hot records fit 48 KiB of LDS");
+    int rc = bind(h);
+    if (rc || n == 0)
+        return rc;
+    std::vector<float> rays(6 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        std::memcpy(&rays[6 * i], origins + 3 * i, 12);
+        std::memcpy(&rays[6 * i + 3], dirs + 3 * i, 12);
+    }
+    DeviceBuffer dRays, dIdx, dOut;
+    HIP_TRY(dRays.alloc(rays.size() * 4));
+    HIP_TRY(dIdx.alloc((size_t)n * 4));
+    HIP_TRY(dOut.alloc((size_t)n * 13 * 4));
+    HIP_TRY(hipMemcpyAsync(dRays.p, rays.data(), rays.size() * 4, hipMemcpyHostToDevice, h->stream));
+    KatTraceArgs a;
+    a.scene = h->view;
+    a.rays = static_cast<const float*>(dRays.p);
+    a.count = n;
+    a.idx = static_cast<int32_t*>(dIdx.p);
+    a.out = static_cast<float*>(dOut.p);
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipError_t le = (hipError_t)(h->strict() ? kajo_kat_trace_strict_launch(&a, grid, h->hotBytes, h->stream)
+                                             : kajo_kat_trace_fast_launch(&a, grid, h->hotBytes, h->stream));
+    if (le != hipSuccess)
+        return failHip(le, "kat trace launch");
+    std::vector<float> out((size_t)n * 13);
+    HIP_TRY(hipMemcpyAsync(objIndex, dIdx.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(out.data(), dOut.p, out.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++) {
+        t[i] = out[13 * (size_t)i];
+        std::memcpy(position + 3 * i, &out[13 * (size_t)i + 1], 12);
+        std::memcpy(normal + 3 * i, &out[13 * (size_t)i + 4], 12);
+        std::memcpy(tangent + 3 * i, &out[13 * (size_t)i + 7], 12);
+        std::memcpy(binormal + 3 * i, &out[13 * (size_t)i + 10], 12);
+    }
+    return KAJO_OK;
+}
+
+int kajo_hip_kat_shade(kajo_hip_t h, int n, const float* origins, const float* dirs, const uint64_t* states, float* rgb,
+                       uint64_t* finalStates)
+{
+    if (!h || n < 0 || !origins || !dirs || !states || !rgb || !finalStates)
+        return fail(KAJO_E_INVALID, "null argument");
+    if (h->hotBytes > 48 * 1024)
+        return fail(KAJO_E_INVALID, "known-answer entry points are limited to scenes whose hot records fit 48 KiB of LDS");
+    int rc = bind(h);
+    if (rc || n == 0)
+        return rc;
+    std::vector<float> rays(6 * (size_t)n);
+    for (int i = 0; i < n; i++) {
+        std::memcpy(&rays[6 * i], origins + 3 * i, 12);
+        std::memcpy(&rays[6 * i + 3], dirs + 3 * i, 12);
+    }
+    DeviceBuffer dRays, dStates, dRgb, dFinal;
+    HIP_TRY(dRays.alloc(rays.size() * 4));
+    HIP_TRY(dStates.alloc((size_t)n * 16));
+    HIP_TRY(dRgb.alloc((size_t)n * 16));
+    HIP_TRY(dFinal.alloc((size_t)n * 16));
+    HIP_TRY(hipMemcpyAsync(dRays.p, rays.data(), rays.size() * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dStates.p, states, (size_t)n * 16, hipMemcpyHostToDevice, h->stream));
+    RenderArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.scene = h->view;
+    a.W = a.H = 1;
+    a.n = 1;
+    a.S = 1.f;
+    a.depthLimit = h->params.depthLimit;
+    a.tileW = 64;
+    a.tileH = 16;
+    a.tilesX = a.tilesY = 1;
+    a.tileCount = 1;
+    a.katRays = static_cast<const float*>(dRays.p);
+    a.katStates = static_cast<const uint64_t*>(dStates.p);
+    a.katRgb = static_cast<float*>(dRgb.p);
+    a.katFinal = static_cast<uint64_t*>(dFinal.p);
+    a.katCount = n;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    hipError_t le = (hipError_t)(h->strict() ? kajo_kat_shade_strict_launch(&a, grid, h->hotBytes, h->stream)
+                                             : kajo_kat_shade_fast_launch(&a, grid, h->hotBytes, h->stream));
+    if (le != hipSuccess)
+        return failHip(le, "kat shade launch");
+    std::vector<float> out4((size_t)n * 4);
+    HIP_TRY(hipMemcpyAsync(out4.data(), dRgb.p, out4.size() * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(finalStates, dFinal.p, (size_t)n * 16, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < n; i++)
+        std::memcpy(rgb + 3 * i, &out4[4 * (size_t)i], 12);
+    return KAJO_OK;
 }
 
 // Diagnostic builds only (-DKAJO_PROFILE): 28 raw block-profile words (16 block counts, 5 stamp sums, spare) behind the work counters.

@@ -295,6 +295,9 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     if (sc.planesRigid) {
         // |det - 1| <= 2^-20 for every plane: t * det is t to within its own rounding, and the
         // second sign test repeats the first
+#ifdef KAJO_UNROLL
+#pragma unroll KAJO_UNROLL
+#endif
         for (int i = 0; i < np; i++) {
             const DFloat4 r = lds.planeRow[i];
             float denom = r.x * d.x + r.y * d.y + r.z * d.z;
@@ -333,6 +336,9 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     if (sc.allTranslated) {
         // every sphere is (centre, radius): a = d.d is one value per ray; the two roots are
         // (-h -+ sqrt(h^2 - a c)) / a
+#ifdef KAJO_UNROLL
+#pragma unroll KAJO_UNROLL
+#endif
         for (int i = 0; i < ns; i++) {
             const DFloat4 s = lds.sphereHot[i];
             F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
@@ -602,12 +608,9 @@ KDEV void stage16(DFloat4* dst, const void* src, int count)
 // into LDS next to the hot records and every sphere is tested. !COLD_LDS (large scenes): the cold
 // records are read from global memory (L2) and the spheres are reached through the uniform grid.
 template <bool COLD_LDS>
-KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
+KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
 {
-    const DSceneView& sc = args.scene;
     const int np = sc.nPlanes, ns = sc.nSpheres;
-
-    // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
     // layout: [planeRow np x16][sphereHot nHot x16]{[planeFrame 3np x16][sphereCold ns x64]
     //         [material (np+ns) x96]}[planeDet np x4][sphereHotOffset ns x4]{[light nL x4]}
     DFloat4* ldsPlaneRow = reinterpret_cast<DFloat4*>(ldsRaw);
@@ -648,6 +651,19 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     lds.sphereHotOffset = ldsSphereOff;
     lds.light = COLD_LDS ? ldsLight : sc.light;
     __syncthreads();
+    return lds;
+}
+
+// KAT (known-answer mode): instead of its pixel's camera paths a lane runs ONE path from a given ray
+// and RNG state and reports its radiance and the RNG state it ends in (kajo_hip_kat_shade).
+template <bool COLD_LDS, bool KAT>
+KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
+{
+    const DSceneView& sc = args.scene;
+    const int np = sc.nPlanes;
+
+    // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
+    const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
 
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;
@@ -661,7 +677,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     const int bxi = wb % (args.tileW >> 3), byi = wb / (args.tileW >> 3);
     const int px = tx * args.tileW + bxi * 8 + (lane & 7);
     const int py = ty * args.tileH + byi * 8 + (lane >> 3);
-    const bool inImage = ownedTile < args.nTilesOwned && px < args.W && py < args.H;
+    const bool inImage = KAT ? (int)slot < args.katCount : (ownedTile < args.nTilesOwned && px < args.W && py < args.H);
 
     const int n = args.n;
     const uint32_t pixelIndex = (uint32_t)(py * args.W + px);
@@ -680,11 +696,12 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // (the handle zeroes the buffer when it is created or reset)
     F3 total = f3(0.0f, 0.0f, 0.0f);
     float totalW = 0.0f;
-    if (inImage) {
+    if (!KAT && inImage) {
         const float4 t = reinterpret_cast<const float4*>(args.tiles)[slot];
         total = f3(t.x, t.y, t.z);
         totalW = t.w;
     }
+    bool katStarted = false;
 
     // ---- per-lane path state ----------------------------------------------------------------
     int mode = inImage ? MODE_NEW : MODE_DONE;
@@ -746,7 +763,24 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         KAJO_STAMP(4); // tail of the previous trip (path bookkeeping, loop back-edge)
         // ---- MODE_NEW: camera ray of the next sample (Renderer.cpp:51-64) ---------------------
         KAJO_PROF(0, mode == MODE_NEW);
-        if (mode == MODE_NEW) {
+        if (KAT && mode == MODE_NEW) {
+            if (katStarted) {
+                mode = MODE_DONE;
+            } else {
+                katStarted = true;
+                O = ld3(args.katRays + 6 * slot);
+                d = ld3(args.katRays + 6 * slot + 3);
+                rng.lo = args.katStates[2 * slot];
+                rng.hi = args.katStates[2 * slot + 1];
+                L = f3(0.0f, 0.0f, 0.0f);
+                T = f3(1.0f, 1.0f, 1.0f);
+                depth = 0;
+                collectEmission = true;
+                pendBsdf = false;
+                mode = MODE_EXTEND;
+            }
+        }
+        if (!KAT && mode == MODE_NEW) {
             if (sampleY == n) { // pass complete: Renderer.cpp:70-71
                 total = total + f3(kdiv(radiance.x, args.S), kdiv(radiance.y, args.S), kdiv(radiance.z, args.S));
                 radiance = f3(0.0f, 0.0f, 0.0f);
@@ -960,10 +994,15 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         if (pathDone) {
             radiance = radiance + L; // Renderer.cpp:66
             mode = MODE_NEW;
+            if (KAT) {
+                reinterpret_cast<float4*>(args.katRgb)[slot] = make_float4(L.x, L.y, L.z, 0.0f);
+                args.katFinal[2 * slot] = rng.lo;
+                args.katFinal[2 * slot + 1] = rng.hi;
+            }
         }
     }
 
-    if (inImage)
+    if (!KAT && inImage)
         reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
 
     if (counting && lane == 0) {
@@ -992,14 +1031,54 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    renderBody<true>(args, ldsRaw);
+    renderBody<true, false>(args, ldsRaw);
 }
 
 // hot records in LDS, cold ones in global memory (large scenes)
 extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_BIG(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    renderBody<false>(args, ldsRaw);
+    renderBody<false, false>(args, ldsRaw);
+}
+
+// known-answer kernels (kajo_hip_kat_shade / kajo_hip_kat_trace): the SAME device functions, fed rays
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KAT_SHADE_NAME(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<false, true>(args, ldsRaw);
+}
+
+extern "C" __global__ void __launch_bounds__(256) KAJO_KAT_TRACE_NAME(const KatTraceArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    const DSceneView& sc = args.scene;
+    const LdsScene lds = stageToLds<false>(sc, ldsRaw);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= args.count)
+        return;
+    const F3 O = ld3(args.rays + 6 * i), d = ld3(args.rays + 6 * i + 3);
+    const Hit h = trace<true>(sc, lds, O, d);
+    float* o = args.out + 13 * i;
+    args.idx[i] = h.id;
+    o[0] = h.t;
+    F3 P = f3(0.0f, 0.0f, 0.0f), N = P, tg = P, bn = P;
+    if (h.id) {
+        P = O + d * h.t;
+        N = hitNormal(sc, lds, h, O, d);
+        if (h.id <= sc.nPlanes) {
+            const DFloat4 t4 = lds.planeFrame[3 * (h.id - 1) + 1], b4 = lds.planeFrame[3 * (h.id - 1) + 2];
+            tg = f3(t4.x, t4.y, t4.z);
+            bn = f3(b4.x, b4.y, b4.z);
+        } else {
+            sphereFrame(N, tg, bn);
+        }
+    }
+    const F3 v[4] = {P, N, tg, bn};
+    for (int k = 0; k < 4; k++) {
+        o[1 + 3 * k] = v[k].x;
+        o[2 + 3 * k] = v[k].y;
+        o[3 + 3 * k] = v[k].z;
+    }
 }
 
 // ---- resolve (Renderer.cpp:73-75 + Image::linearToSRGB / colorToRGBA8, Image.cpp:14-27) ----------

@@ -27,3 +27,15 @@ extern "C" int KAJO_CAT(KAJO_RESOLVE_NAME, _launch)(const void* frame, int count
                        static_cast<const float4*>(frame), count, passes, static_cast<uint32_t*>(dst));
     return (int)hipGetLastError();
 }
+
+extern "C" int KAJO_CAT(KAJO_KAT_SHADE_NAME, _launch)(const RenderArgs* args, unsigned grid, size_t ldsBytes, void* stream)
+{
+    hipLaunchKernelGGL(KAJO_KAT_SHADE_NAME, dim3(grid), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), *args);
+    return (int)hipGetLastError();
+}
+
+extern "C" int KAJO_CAT(KAJO_KAT_TRACE_NAME, _launch)(const KatTraceArgs* args, unsigned grid, size_t ldsBytes, void* stream)
+{
+    hipLaunchKernelGGL(KAJO_KAT_TRACE_NAME, dim3(grid), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), *args);
+    return (int)hipGetLastError();
+}

@@ -20,6 +20,21 @@ struct RenderArgs
     int32_t tileW, tileH, tilesX, tilesY;
     int32_t tileIndex, tileCount, nTilesOwned;
     unsigned long long* counters; // [0] traversals, [1] vertices, [2] lane slots; may be null
+    // known-answer mode (kajo_hip_kat_shade): lane i runs ONE path from a given ray and RNG state
+    const float* katRays;         // [katCount][6] origin, direction
+    const uint64_t* katStates;    // [katCount][2]
+    float* katRgb;                // [katCount][4]
+    uint64_t* katFinal;           // [katCount][2]
+    int32_t katCount;
+};
+
+struct KatTraceArgs
+{
+    DSceneView scene;
+    const float* rays; // [count][6]
+    int32_t count;
+    int32_t* idx;      // [count]
+    float* out;        // [count][13]: t, position, normal, tangent, binormal
 };
 
 // tile-buffer slot of pixel (x, y): tiles are dealt round-robin to `tileCount` owners; inside a

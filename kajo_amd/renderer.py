@@ -94,6 +94,29 @@ class HipRenderer:
         capi.check(self._L.kajo_hip_counters(self._h, C.byref(c)))
         return {k: getattr(c, k) for k, _ in capi.KajoCounters._fields_}
 
+    # -- known-answer hooks ----------------------------------------------------------------
+    def kat_trace(self, origins, dirs):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        n = o.shape[0]
+        idx = np.zeros(n, np.int32)
+        t = np.zeros(n, np.float32)
+        pos, nor, tan, bi = (np.zeros((n, 3), np.float32) for _ in range(4))
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        capi.check(self._L.kajo_hip_kat_trace(self._h, n, p(o), p(d), p(idx), p(t), p(pos), p(nor), p(tan), p(bi)))
+        return dict(idx=idx, t=t, position=pos, normal=nor, tangent=tan, binormal=bi)
+
+    def kat_shade(self, origins, dirs, states):
+        o = np.ascontiguousarray(origins, np.float32)
+        d = np.ascontiguousarray(dirs, np.float32)
+        st = np.ascontiguousarray(states, np.uint64)
+        n = o.shape[0]
+        rgb = np.zeros((n, 3), np.float32)
+        fin = np.zeros((n, 2), np.uint64)
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        capi.check(self._L.kajo_hip_kat_shade(self._h, n, p(o), p(d), p(st), p(rgb), p(fin)))
+        return rgb, fin
+
     # -- multi-GPU plumbing ----------------------------------------------------------------
     def tile_buffer(self):
         ptr, nbytes = C.c_void_p(), C.c_size_t()

@@ -40,6 +40,7 @@ def bits_equal(a, b):
 
 
 STRICT_CASES = [
+    ("spheres_a1", 256, 256, 16, 1, 1),    # BASELINE configs[0] (C1) exactly: 256x256, 16 spp, 1 bounce
     # scene key, W, H, S, passes, depth
     ("spheres_a1", 64, 64, 16, 1, 1),      # BASELINE configs[0] shape (C1) at 64x64
     ("spheres_a1", 64, 64, 32, 2, 8),

@@ -167,27 +167,27 @@ void destroy(KajoHip* h)
 {
     if (!h)
         return;
-    hipSetDevice(h->device);
+    (void)hipSetDevice(h->device);
     if (h->stream)
-        hipStreamSynchronize(h->stream);
+        (void)hipStreamSynchronize(h->stream);
     for (auto& pr : h->pending) {
-        hipEventDestroy(pr.first);
-        hipEventDestroy(pr.second);
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
     }
     for (hipEvent_t e : h->eventPool)
-        hipEventDestroy(e);
+        (void)hipEventDestroy(e);
     for (void* p : h->sceneBuffers)
-        hipFree(p);
+        (void)hipFree(p);
     if (h->tiles)
-        hipFree(h->tiles);
+        (void)hipFree(h->tiles);
     if (h->frame)
-        hipFree(h->frame);
+        (void)hipFree(h->frame);
     if (h->argb)
-        hipFree(h->argb);
+        (void)hipFree(h->argb);
     if (h->counters)
-        hipFree(h->counters);
+        (void)hipFree(h->counters);
     if (h->ownStream && h->stream)
-        hipStreamDestroy(h->stream);
+        (void)hipStreamDestroy(h->stream);
     delete h;
 }
 

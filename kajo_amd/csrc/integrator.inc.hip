@@ -945,12 +945,15 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // the reflector, outside the lobe for Phong) discards the sample either way, so the
                 // trace is skipped for it.
                 const float pb = bsdfProbability(vKind, vExp, vR, vN, l);
-                if (pl == 0.0f || pb == 0.0f) {
+                // A light at or below the horizon contributes max(0, n.l) = 0 whatever the shadow ray
+                // finds (the sum stays as it is: x + (+-0) == x), so that walk is skipped as well.
+                const float cosL = fmaxf(0.0f, dot(vN, l));
+                if (pl == 0.0f || pb == 0.0f || cosL == 0.0f) {
                     lightK++;
                     continue;
                 }
                 const F3 Le = ld3(lds.material[np + si].emission);
-                pendContrib = ((krcp(pb + pl) * bsdfEvaluate(vKind, vColor, vExp, vR, vN, l)) * fmaxf(0.0f, dot(vN, l))) * Le;
+                pendContrib = ((krcp(pb + pl) * bsdfEvaluate(vKind, vColor, vExp, vR, vN, l)) * cosL) * Le;
                 O = vP + l * kEps;
                 d = l;
                 mode = MODE_SHADOW;

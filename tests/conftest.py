@@ -9,10 +9,6 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-# numpy probes the subnormal behaviour of the FPU at import; libraries built with
-# -ffast-math (the reference build) set flush-to-zero in their constructors, which only makes
-# numpy print a warning.
-warnings.filterwarnings("ignore", message="The value of the smallest subnormal")
 
 
 def pytest_configure(config):

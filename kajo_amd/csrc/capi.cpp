@@ -97,6 +97,11 @@ struct KajoHip
     void* argb = nullptr;    // uint32[W*H], lazily
     bool frameValid = false;
     unsigned long long* counters = nullptr; // device [4]
+    // launch-order feedback (render_args.h): per-wave loop trips of the last launch, block order for the next
+    uint32_t* waveTrips = nullptr;   // device [grid * 4]
+    uint32_t* blockOrder = nullptr;  // device [grid]
+    bool orderValid = false, tripsPending = false;
+    unsigned gridBlocks = 0;
     int passesDone = 0;
     size_t ldsBytes = 0, hotBytes = 0;
     int coldInLds = 1;
@@ -186,6 +191,10 @@ void destroy(KajoHip* h)
         (void)hipFree(h->argb);
     if (h->counters)
         (void)hipFree(h->counters);
+    if (h->waveTrips)
+        (void)hipFree(h->waveTrips);
+    if (h->blockOrder)
+        (void)hipFree(h->blockOrder);
     if (h->ownStream && h->stream)
         (void)hipStreamDestroy(h->stream);
     delete h;
@@ -366,6 +375,14 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->counters), 32 * sizeof(unsigned long long)));
         CREATE_TRY(hipMemsetAsync(h->counters, 0, 32 * sizeof(unsigned long long), h->stream));
     }
+    {
+        const int wavesPerTile = (p.tileW / 8) * (p.tileH / 8);
+        h->gridBlocks = (unsigned)((long long)h->nTilesOwned * wavesPerTile / 4);
+        if (h->gridBlocks && !(p.flags & KAJO_FLAG_NO_REORDER)) {
+            CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->waveTrips), (size_t)h->gridBlocks * 4 * sizeof(uint32_t)));
+            CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->blockOrder), (size_t)h->gridBlocks * sizeof(uint32_t)));
+        }
+    }
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     *out = h;
@@ -430,9 +447,10 @@ int kajo_hip_render(kajo_hip_t h, int passes)
     a.nTilesOwned = h->nTilesOwned;
     a.counters = h->counters;
 
-    const int wavesPerTile = (p.tileW / 8) * (p.tileH / 8);
     const unsigned block = 256;
-    const unsigned grid = (unsigned)((long long)h->nTilesOwned * wavesPerTile / 4);
+    const unsigned grid = h->gridBlocks;
+    a.blockOrder = h->orderValid ? h->blockOrder : nullptr;
+    a.waveTrips = (h->waveTrips && !h->orderValid) ? h->waveTrips : nullptr; // measure once, on the first launch
     const int perLaunch = p.passesPerLaunch > 0 ? p.passesPerLaunch : 16;
     int left = passes;
     while (left > 0) {
@@ -449,6 +467,9 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             return failHip(le, "render kernel launch");
         HIP_TRY(hipEventRecord(e1, h->stream));
         h->pending.emplace_back(e0, e1);
+        if (a.waveTrips)
+            h->tripsPending = true;
+        a.waveTrips = nullptr; // later launches of this call keep the first measurement
         h->launches++;
         h->passesDone += now;
         left -= now;
@@ -456,6 +477,30 @@ int kajo_hip_render(kajo_hip_t h, int passes)
     h->frameValid = false;
     return KAJO_OK;
 }
+
+namespace
+{
+
+// Longest-processing-time-first order of the workgroups from the trips the first launch recorded
+// (a block runs as long as its slowest wave).
+int updateBlockOrder(KajoHip* h)
+{
+    h->tripsPending = false;
+    const unsigned n = h->gridBlocks;
+    std::vector<uint32_t> trips((size_t)n * 4);
+    HIP_TRY(hipMemcpy(trips.data(), h->waveTrips, trips.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> cost(n), order(n);
+    for (unsigned b = 0; b < n; b++) {
+        cost[b] = std::max(std::max(trips[4 * b], trips[4 * b + 1]), std::max(trips[4 * b + 2], trips[4 * b + 3]));
+        order[b] = b;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
+    HIP_TRY(hipMemcpy(h->blockOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->orderValid = true;
+    return KAJO_OK;
+}
+
+} // namespace
 
 int kajo_hip_wait(kajo_hip_t h)
 {
@@ -465,6 +510,8 @@ int kajo_hip_wait(kajo_hip_t h)
     if (rc)
         return rc;
     HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->tripsPending && (rc = updateBlockOrder(h)))
+        return rc;
     return drainEvents(h);
 }
 

@@ -667,7 +667,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x; // index into the tile buffer
+    const uint32_t logicalBlock = (!KAT && args.blockOrder) ? args.blockOrder[blockIdx.x] : blockIdx.x;
+    const uint32_t slot = logicalBlock * blockDim.x + threadIdx.x; // index into the tile buffer
     const int wave = (int)(slot >> 6);
     const int wavesPerTile = (args.tileW >> 3) * (args.tileH >> 3);
     const int ownedTile = wave / wavesPerTile;
@@ -759,7 +760,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #ifdef KAJO_PROFILE
     stampLast = __builtin_amdgcn_s_memtime();
 #endif
+    uint32_t trips = 0;
     for (;;) {
+        trips++;
         KAJO_STAMP(4); // tail of the previous trip (path bookkeeping, loop back-edge)
         // ---- MODE_NEW: camera ray of the next sample (Renderer.cpp:51-64) ---------------------
         KAJO_PROF(0, mode == MODE_NEW);
@@ -1007,6 +1010,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     if (!KAT && inImage)
         reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
+    if (!KAT && args.waveTrips && lane == 0)
+        args.waveTrips[slot >> 6] = trips;
 
     if (counting && lane == 0) {
         atomicAdd(&args.counters[0], ctrTraversals);

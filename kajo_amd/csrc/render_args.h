@@ -20,6 +20,11 @@ struct RenderArgs
     int32_t tileW, tileH, tilesX, tilesY;
     int32_t tileIndex, tileCount, nTilesOwned;
     unsigned long long* counters; // [0] traversals, [1] vertices, [2] lane slots; may be null
+    // Launch-order feedback: blocks are dispatched in blockIdx order; the host sorts them by the cost the
+    // previous launch measured (longest first) so that the launch does not end on its most expensive
+    // workgroups. Pure scheduling: the buffer slot of a pixel does not depend on it.
+    const uint32_t* blockOrder;   // [grid] logical block run by physical block i; null = identity
+    uint32_t* waveTrips;          // [grid * 4] loop trips of every wave of the launch; null = not recorded
     // known-answer mode (kajo_hip_kat_shade): lane i runs ONE path from a given ray and RNG state
     const float* katRays;         // [katCount][6] origin, direction
     const uint64_t* katStates;    // [katCount][2]

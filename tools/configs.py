@@ -11,6 +11,7 @@ a1=Scene.from_npz(z,'spheres_a1/','spheres a1'); a169=Scene.from_npz(z,'spheres_
 caus=Scene.from_npz(z,'caustics_a169/','caustics (3 lights)')
 cases=[('C1 256x256 S=16 depth1 1 pass',a1,256,256,16,1,1),
        ('C2 1080p 16xS32',a169,1920,1080,32,16,8),
+       ('C2 alt: 1080p 1 pass x S=512 (n=22, 484 paths/px)',a169,1920,1080,512,1,8),
        ('C3/GPU: 4K 16xS32 (1 GPU, 512 of 2048 spp)',a169,3840,2160,32,16,8),
        ('C4 caustics 1080p 16xS32 (of 128) depth 8',caus,1920,1080,32,16,8),
        ('C5 1000 spheres/16 lights 4K 1xS32 (of 32)',stress_scene(a169,1000,16),3840,2160,32,1,8),

@@ -351,11 +351,6 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         destroy(h);
         return fail(KAJO_E_INVALID, "scene exceeds the 160 KiB LDS staging limit (hot records)");
     }
-    if (h->ldsBytes > 48 * 1024) {
-        CREATE_TRY((hipError_t)(h->strict() ? kajo_render_strict_set_lds(h->coldInLds, h->ldsBytes)
-                                            : kajo_render_fast_set_lds(h->coldInLds, h->ldsBytes)));
-    }
-
     // ---- tiles -----------------------------------------------------------------------------
     TileMap& m = h->map;
     m.W = width;
@@ -391,6 +386,13 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         if (h->gridBlocks && !(p.flags & KAJO_FLAG_NO_REORDER)) {
             CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->waveTrips), (size_t)h->gridBlocks * h->wavesPerBlock * sizeof(uint32_t)));
             CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->blockOrder), (size_t)h->gridBlocks * sizeof(uint32_t)));
+        }
+    }
+    {
+        const size_t ldsTotal = ((h->ldsBytes + 15) & ~(size_t)15) + (size_t)h->wavesPerBlock * 64 * 4 * 16;
+        if (ldsTotal > 48 * 1024) {
+            CREATE_TRY((hipError_t)(h->strict() ? kajo_render_strict_set_lds(h->coldInLds, ldsTotal)
+                                                : kajo_render_fast_set_lds(h->coldInLds, ldsTotal)));
         }
     }
     CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -456,11 +458,14 @@ int kajo_hip_render(kajo_hip_t h, int passes)
     a.tileCount = p.tileCount;
     a.nTilesOwned = h->nTilesOwned;
     a.counters = h->counters;
+    a.mailboxOffset = (uint32_t)((h->ldsBytes + 15) & ~(size_t)15);
 
     const unsigned block = 64 * h->wavesPerBlock;
     const unsigned grid = h->gridBlocks;
     a.blockOrder = h->orderValid ? h->blockOrder : nullptr;
     a.waveTrips = (h->waveTrips && !h->orderValid) ? h->waveTrips : nullptr; // measure once, on the first launch
+    // scene copy + one mailbox (64 lanes x 4 passes x float4) per wave of the workgroup
+    const size_t ldsTotal = a.mailboxOffset + (size_t)h->wavesPerBlock * 64 * 4 * 16;
     const int perLaunch = p.passesPerLaunch > 0 ? p.passesPerLaunch : 16;
     int left = passes;
     while (left > 0) {
@@ -471,8 +476,8 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         if ((rc = getEvent(h, &e0)) || (rc = getEvent(h, &e1)))
             return rc;
         HIP_TRY(hipEventRecord(e0, h->stream));
-        hipError_t le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, h->ldsBytes, h->stream)
-                                                 : kajo_render_fast_launch(&a, h->coldInLds, grid, block, h->ldsBytes, h->stream));
+        hipError_t le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream)
+                                                 : kajo_render_fast_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream));
         if (le != hipSuccess)
             return failHip(le, "render kernel launch");
         HIP_TRY(hipEventRecord(e1, h->stream));

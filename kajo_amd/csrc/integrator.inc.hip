@@ -589,6 +589,10 @@ enum : int
 
 } // namespace
 
+#ifndef KAJO_STEAL_WINDOW
+#define KAJO_STEAL_WINDOW 4 // passes at the end of a launch that an idle lane may take over
+#endif
+
 #ifndef KAJO_WAVES_PER_SIMD
 #define KAJO_WAVES_PER_SIMD 4 // register budget: 512 / 4 = 128 VGPRs per lane
 #endif
@@ -665,6 +669,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
 
+    // per-wave mailbox for taken-over passes: [lane][KAJO_STEAL_WINDOW] float4, behind the scene copy
+    DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.mailboxOffset) + (threadIdx.x >> 6) * (64 * KAJO_STEAL_WINDOW);
+
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;
     const uint32_t logicalBlock = (!KAT && args.blockOrder) ? args.blockOrder[blockIdx.x] : blockIdx.x;
@@ -689,9 +696,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     const F3 p1 = ld3(sc.p1), dp2 = ld3(sc.dp2), dp3 = ld3(sc.dp3), origin = ld3(sc.origin);
     const F3 background = ld3(sc.background);
-    // x * pixelWidth and (H - y) * pixelHeight of Renderer.cpp:56-57 are constants of the lane
+    // x * pixelWidth and (H - y) * pixelHeight of Renderer.cpp:56-57 are constants of the pixel
     const float pixX = px * args.pixelWidth;
     const float pixY = (args.H - py) * args.pixelHeight;
+    // The pixel whose pass the lane is rendering right now: its own, or -- near the end of the wave's
+    // life -- one taken over from a lane that still has whole passes left (see "pass stealing" below).
+    uint32_t curKeyA = keyA;
+    float curPixX = pixX, curPixY = pixY;
 
     // accumulated radiance of the pixel (Renderer.cpp:70-71), continued across launches
     // (the handle zeroes the buffer when it is created or reset)
@@ -706,8 +717,18 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     // ---- per-lane path state ----------------------------------------------------------------
     int mode = inImage ? MODE_NEW : MODE_DONE;
-    int pass = args.firstPass;
+    int pass = args.firstPass;                          // pass being rendered (own or taken over)
     const int lastPass = args.firstPass + args.nPasses; // exclusive
+    // Pass stealing. A pass of a pixel is a self-contained piece of work (its n*n paths have their own
+    // streams, its sum enters the pixel's total as one term), so a lane that has finished its own pixel
+    // takes over the LAST not-yet-started pass of a lane that still has several to go, renders it, and
+    // leaves radiance / S in a mailbox in LDS; the owner adds the mailbox terms after its own passes, in
+    // pass order -- the float sums are formed exactly as without stealing. Only the last KAJO_STEAL_WINDOW
+    // passes of a launch can be given away (that is all the imbalance there is, and bounds the mailbox).
+    int ownPass = args.firstPass; // next pass of the lane's own pixel
+    int myEnd = inImage ? lastPass : args.firstPass; // own passes [ownPass, myEnd); shrinks when one is taken over
+    int stolenFrom = -1;          // lane whose pass is being rendered, or -1
+    const int stealBase = lastPass - KAJO_STEAL_WINDOW > args.firstPass ? lastPass - KAJO_STEAL_WINDOW : args.firstPass;
     int sampleX = 0, sampleY = 0;
     F3 radiance = f3(0.0f, 0.0f, 0.0f); // sum over the pixel's samples of this pass
     Rng rng{0, 0};
@@ -760,6 +781,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #ifdef KAJO_PROFILE
     stampLast = __builtin_amdgcn_s_memtime();
 #endif
+#if !KAJO_STRICT
+    const float invS = __builtin_amdgcn_rcpf(args.S);
+#endif
     uint32_t trips = 0;
     for (;;) {
         trips++;
@@ -785,15 +809,54 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
         if (!KAT && mode == MODE_NEW) {
             if (sampleY == n) { // pass complete: Renderer.cpp:70-71
-                total = total + f3(kdiv(radiance.x, args.S), kdiv(radiance.y, args.S), kdiv(radiance.z, args.S));
+#if KAJO_STRICT
+                const F3 term = f3(radiance.x / args.S, radiance.y / args.S, radiance.z / args.S);
+#else
+                const F3 term = radiance * invS;
+#endif
+                if (stolenFrom >= 0) {
+                    mailbox[stolenFrom * KAJO_STEAL_WINDOW + (pass - stealBase)] = DFloat4{term.x, term.y, term.z, 0.0f};
+                    stolenFrom = -1;
+                } else {
+                    total = total + term;
+                    ownPass++;
+                }
                 radiance = f3(0.0f, 0.0f, 0.0f);
                 sampleY = 0;
-                pass++;
+                pass = ownPass;
+                curKeyA = keyA;
+                curPixX = pixX;
+                curPixY = pixY;
             }
-            if (pass >= lastPass) {
-                mode = MODE_DONE;
-            } else {
-                uint32_t a = keyA, c = keyC, dd = keyD;
+            // out of own passes: take one over, or retire when nobody has one to give
+            unsigned long long idleMask = __ballot(stolenFrom < 0 && ownPass >= myEnd);
+            while (idleMask) { // wave-uniform; only in the last stretch of the wave's life
+                const int give = myEnd - 1; // the pass this lane could give away
+                const unsigned long long giverMask = __ballot(mode != MODE_DONE && stolenFrom < 0 && give > ownPass && give >= stealBase);
+                if (giverMask == 0ull) {
+                    if (stolenFrom < 0 && ownPass >= myEnd)
+                        mode = MODE_DONE;
+                    break;
+                }
+                // lowest idle lane takes the last pass of the lowest giver
+                const int thief = __builtin_ctzll(idleMask), giver = __builtin_ctzll(giverMask);
+                const int takenPass = __builtin_amdgcn_readlane(myEnd, giver) - 1;
+                const uint32_t gKey = (uint32_t)__builtin_amdgcn_readlane((int)keyA, giver);
+                const float gX = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pixX), giver));
+                const float gY = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pixY), giver));
+                if (lane == giver)
+                    myEnd = takenPass;
+                if (lane == thief) {
+                    stolenFrom = giver;
+                    pass = takenPass;
+                    curKeyA = gKey;
+                    curPixX = gX;
+                    curPixY = gY;
+                }
+                idleMask &= idleMask - 1; // next idle lane
+            }
+            if (mode == MODE_NEW && (stolenFrom >= 0 || ownPass < myEnd)) {
+                uint32_t a = curKeyA, c = keyC, dd = keyD;
                 uint32_t b = ((uint32_t)(sampleY * n + sampleX) | ((uint32_t)pass << 16)) ^ 0x3320646eu;
                 KAJO_QUARTER_ROUND(a, b, c, dd);
                 KAJO_QUARTER_ROUND(a, b, c, dd);
@@ -803,8 +866,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 rngStep(rng);
                 float offX = unit(lane32((uint32_t)rng.lo));
                 float offY = unit(lane32((uint32_t)(rng.lo >> 32)));
-                float sx = pixX + sampleX * args.sampleWidth + offX * args.sampleWidth;
-                float sy = pixY + sampleY * args.sampleHeight + offY * args.sampleHeight;
+                float sx = curPixX + sampleX * args.sampleWidth + offX * args.sampleWidth;
+                float sy = curPixY + sampleY * args.sampleHeight + offY * args.sampleHeight;
                 F3 dir = p1 + dp2 * sx + dp3 * sy - origin;
                 d = normalize(dir);
                 O = origin;
@@ -821,10 +884,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 mode = MODE_EXTEND;
             }
         }
-        const bool active = mode != MODE_DONE;
-        const unsigned long long activeMask = __ballot(active);
-        if (activeMask == 0ull)
+        const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
+        if (aliveMask == 0ull)
             break;
+        const unsigned long long activeMask = __ballot(mode == MODE_EXTEND || mode == MODE_SHADOW); // lanes with a ray
 
         KAJO_STAMP(0); // camera-ray block
         // ---- one ray per lane through the whole scene ------------------------------------------
@@ -1008,8 +1071,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
     }
 
-    if (!KAT && inImage)
+    if (!KAT && inImage) {
+        // passes of this pixel that other lanes rendered, in pass order
+        for (int p = myEnd; p < lastPass; p++) {
+            const DFloat4 t = mailbox[lane * KAJO_STEAL_WINDOW + (p - stealBase)];
+            total = total + f3(t.x, t.y, t.z);
+        }
         reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
+    }
     if (!KAT && args.waveTrips && lane == 0)
         args.waveTrips[slot >> 6] = trips;
 

@@ -316,6 +316,9 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         CREATE_TRY(upload(st.gridCellStart, &cellStart, h->sceneBuffers));
         CREATE_TRY(upload(st.gridItems, &items, h->sceneBuffers));
         v.grid.enabled = st.gridEnabled;
+        v.grid.nCells = st.gridEnabled ? (int32_t)st.gridCellStart.size() - 1 : 0;
+        v.grid.nItems = (int32_t)st.gridItems.size();
+        v.grid.inLds = 0;
         v.grid.cellStart = cellStart;
         v.grid.items = items;
         for (int k = 0; k < 3; k++) {
@@ -344,9 +347,17 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     const size_t hotBytes = (size_t)v.nPlanes * (16 + 4) + (size_t)v.nSphereHot * 16 + (size_t)v.nSpheres * 4;
     const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * sizeof(DMaterial) +
                              (size_t)v.nLights * 4;
-    h->hotBytes = hotBytes;
+    size_t gridBytes = 0;
+    if (st.gridEnabled) {
+        gridBytes = (st.gridCellStart.size() + st.gridItems.size()) * sizeof(uint32_t);
+        // four 4-wave workgroups per CU share 160 KiB: hot records + grid + mailboxes must stay under 40 KiB
+        v.grid.inLds = hotBytes + gridBytes + 4 * 4096 <= 40 * 1024;
+        if (!v.grid.inLds)
+            gridBytes = 0;
+    }
+    h->hotBytes = hotBytes + gridBytes; // what the big-scene staging (and the known-answer kernels) put in LDS
     h->coldInLds = hotBytes + coldBytes <= 40 * 1024 && !st.gridEnabled;
-    h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0);
+    h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0) + gridBytes;
     if (h->ldsBytes > 160 * 1024) {
         destroy(h);
         return fail(KAJO_E_INVALID, "scene exceeds the 160 KiB LDS staging limit (hot records)");

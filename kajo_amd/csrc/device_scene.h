@@ -75,6 +75,8 @@ struct DGrid
     float cell[3], invCell[3];
     const uint32_t* cellStart; // [dim.x * dim.y * dim.z + 1]
     const uint32_t* items;     // sphere indices, ascending within a cell
+    int32_t nCells, nItems;
+    int32_t inLds;             // the two arrays are staged into LDS behind the hot records
 };
 
 struct DSceneView // device pointers + counts, passed to the kernels by value

@@ -153,6 +153,8 @@ struct LdsScene
     const DSphereCold* sphereCold;
     const DMaterial* material;
     const int32_t* light;
+    const uint32_t* gridCellStart; // LDS copy when it fits (DGrid.inLds), else the global arrays
+    const uint32_t* gridItems;
 };
 
 // One sphere of Raytracer.cpp:21-72 up to (not including) processIntersection: returns false when the
@@ -250,9 +252,9 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
     const float dz = d.z == 0.0f ? inf : g.cell[2] * __builtin_fabsf(iz_);
     for (int guard = g.dim[0] + g.dim[1] + g.dim[2] + 3; guard > 0; guard--) {
         const int cell = (cz * g.dim[1] + cy) * g.dim[0] + cx;
-        const uint32_t e = g.cellStart[cell + 1];
-        for (uint32_t k = g.cellStart[cell]; k < e; k++) {
-            const int i = (int)g.items[k];
+        const uint32_t e = lds.gridCellStart[cell + 1];
+        for (uint32_t k = lds.gridCellStart[cell]; k < e; k++) {
+            const int i = (int)lds.gridItems[k];
             float ts, th;
             const bool valid = sphereCandidate(sc, lds, i, O, d, aT, iaT, ts, th);
             const int id = np + 1 + i;
@@ -654,6 +656,19 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     lds.planeDet = ldsPlaneDet;
     lds.sphereHotOffset = ldsSphereOff;
     lds.light = COLD_LDS ? ldsLight : sc.light;
+    lds.gridCellStart = sc.grid.cellStart;
+    lds.gridItems = sc.grid.items;
+    if (!COLD_LDS && sc.grid.enabled && sc.grid.inLds) {
+        // the DDA reads two cell offsets per step: from LDS that is ~64 cycles, from L2 ~500
+        uint32_t* cs = reinterpret_cast<uint32_t*>(ldsSphereOff + ns);
+        uint32_t* it = cs + sc.grid.nCells + 1;
+        for (int i = threadIdx.x; i <= sc.grid.nCells; i += blockDim.x)
+            cs[i] = sc.grid.cellStart[i];
+        for (int i = threadIdx.x; i < sc.grid.nItems; i += blockDim.x)
+            it[i] = sc.grid.items[i];
+        lds.gridCellStart = cs;
+        lds.gridItems = it;
+    }
     __syncthreads();
     return lds;
 }

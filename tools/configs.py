@@ -15,7 +15,8 @@ cases=[('C1 256x256 S=16 depth1 1 pass',a1,256,256,16,1,1),
        ('C3/GPU: 4K 16xS32 (1 GPU, 512 of 2048 spp)',a169,3840,2160,32,16,8),
        ('C4 caustics 1080p 16xS32 (of 128) depth 8',caus,1920,1080,32,16,8),
        ('C5 1000 spheres/16 lights 4K 1xS32 (of 32)',stress_scene(a169,1000,16),3840,2160,32,1,8),
-       ('C5 at 1080p 1xS32',stress_scene(a169,1000,16),1920,1080,32,1,8)]
+       ('C5 at 1080p 1xS32',stress_scene(a169,1000,16),1920,1080,32,1,8),
+       ('C5 at 1080p 8xS32',stress_scene(a169,1000,16),1920,1080,32,8,8)]
 sel=sys.argv[1:] 
 for name,sc,W,H,S,passes,depth in cases:
     if sel and not any(s in name for s in sel): continue

@@ -108,3 +108,21 @@ def test_fast_on_caustics_and_stress(scenes):
     # 150 small Phong/diffuse spheres at 32 paths per pixel: a handful of flipped paths decide the statistics;
     # measured 1.2-1.8 x the reference's own two-build difference
     fast_close(stress_scene(scenes["spheres_a169"], 150, 4, seed=3), 64, 36, passes=2, slack=2.5)
+
+
+def test_maximum_sizes(scenes):
+    """4K frame (BASELINE configs[2] size): every tile is written, a crop agrees with the oracle bit for bit
+    (STRICT), two runs agree; and the pass counter refuses to run past the 16 bits the stream key holds."""
+    from kajo_amd import capi
+    sc = scenes["spheres_a169"]
+    W, H = 3840, 2160
+    with HipRenderer(sc, W, H, spp=4, strict=True) as r:
+        a = r.render(1).radiance()
+        with pytest.raises(capi.KajoError) as e:
+            r.render(70000)
+        assert e.value.code == -1
+    assert np.isfinite(a[..., :3]).mean() > 0.9999 and (a[..., :3] != 0).any(axis=(0, 2)).all()
+    x0, y0, w, h = 3700, 2100, 96, 48   # bottom-right corner region (last tiles, partial tile row)
+    want = OracleLib("oracle").create(sc, 1).render(W, H, S=4, passes=1, seed=SEED, rect=(x0, y0, w, h))[y0:y0 + h, x0:x0 + w, :3]
+    got = a[y0:y0 + h, x0:x0 + w, :3]
+    assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all()

@@ -19,6 +19,14 @@ template<int KIND> __global__ void __launch_bounds__(256) k(float* out, int iter
       u0*=u1|1;u1*=u2|1;u2*=u3|1;u3*=u4|1;u4*=u5|1;u5*=u6|1;u6*=u7|1;u7*=u0|1;
     } else if(KIND==4){ // add_u32 + xor + rot (ARX)
       u0+=u1;u1^=u0;u1=(u1<<7)|(u1>>25);u2+=u3;u3^=u2;u3=(u3<<9)|(u3>>23);u4+=u5;u5^=u4;u5=(u5<<13)|(u5>>19);u6+=u7;u7^=u6;u7=(u7<<11)|(u7>>21);
+    } else if(KIND==6){ // packed fma: 2 FMAs per instruction
+      typedef float v2 __attribute__((ext_vector_type(2)));
+      v2 a2={a,a}, b2={b,b};
+      v2 p0={x0,x1},p1={x2,x3},p2={x4,x5},p3={x6,x7};
+      asm volatile("v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                   "v_pk_fma_f32 %0, %0, %4, %5\n v_pk_fma_f32 %1, %1, %4, %5\n v_pk_fma_f32 %2, %2, %4, %5\n v_pk_fma_f32 %3, %3, %4, %5\n"
+                   : "+v"(p0),"+v"(p1),"+v"(p2),"+v"(p3) : "v"(a2),"v"(b2));
+      x0=p0.x;x1=p0.y;x2=p1.x;x3=p1.y;x4=p2.x;x5=p2.y;x6=p3.x;x7=p3.y;
     } else if(KIND==5){ // mul f32
       x0*=a;x1*=a;x2*=a;x3*=a;x4*=a;x5*=a;x6*=a;x7*=a;
     }
@@ -40,5 +48,6 @@ template<int KIND> int run(const char* name,int opsPerIter,int wavesPerSimd){
 }
 int main(){
   for(int w: {1,2,4,8}){ run<0>("fma",8,w); }
+  for(int w: {1,2,4,8}){ run<6>("pk_fma(x2)",8,w); }
   for(int w: {1,4}){ run<5>("mul",8,w); run<1>("rcp",8,w); run<2>("cmp+sel+mul",24,w); run<3>("mul_lo_u32",16,w); run<4>("arx",16,w); }
 }

@@ -138,6 +138,8 @@ int kajo_hip_kat_trace(kajo_hip_t h, int n, const float* origins, const float* d
                        float* position, float* normal, float* tangent, float* binormal);
 int kajo_hip_kat_shade(kajo_hip_t h, int n, const float* origins, const float* dirs, const uint64_t* states, float* rgb,
                        uint64_t* finalStates);
+/* include/kajo_strictmath.h evaluated on the device, element-wise: fn 0 sin, 1 cos, 2 asin, 3 acos, 4 pow(x, y). */
+int kajo_hip_kat_strictmath(kajo_hip_t h, int fn, int n, const float* x, const float* y, float* out);
 
 const char* kajo_hip_last_error(void);
 const char* kajo_hip_version(void);

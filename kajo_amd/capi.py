@@ -28,6 +28,7 @@ EXPORTS = [
     "kajo_hip_reset", "kajo_hip_resolve_argb8", "kajo_hip_read_radiance", "kajo_hip_resolve_argb8_device",
     "kajo_hip_tile_buffer", "kajo_hip_compose", "kajo_hip_set_stream", "kajo_hip_counters",
     "kajo_hip_stage_scene", "kajo_hip_last_error", "kajo_hip_version", "kajo_hip_kat_trace", "kajo_hip_kat_shade",
+    "kajo_hip_kat_strictmath",
 ]
 
 
@@ -87,6 +88,7 @@ def lib():
         L.kajo_hip_default_params.argtypes = [C.POINTER(KajoParams)]
         L.kajo_hip_kat_trace.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         L.kajo_hip_kat_shade.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
+        L.kajo_hip_kat_strictmath.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = L
     return _lib
 

@@ -34,6 +34,7 @@ int kajo_kat_shade_fast_launch(const RenderArgs*, unsigned grid, size_t lds, voi
 int kajo_kat_shade_strict_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_kat_trace_fast_launch(const KatTraceArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_kat_trace_strict_launch(const KatTraceArgs*, unsigned grid, size_t lds, void* stream);
+int kajo_kat_math_launch(int fn, int n, const void* x, const void* y, void* out, void* stream);
 }
 
 namespace
@@ -743,6 +744,27 @@ int kajo_hip_kat_shade(kajo_hip_t h, int n, const float* origins, const float* d
     HIP_TRY(hipStreamSynchronize(h->stream));
     for (int i = 0; i < n; i++)
         std::memcpy(rgb + 3 * i, &out4[4 * (size_t)i], 12);
+    return KAJO_OK;
+}
+
+int kajo_hip_kat_strictmath(kajo_hip_t h, int fn, int n, const float* x, const float* y, float* out)
+{
+    if (!h || n < 0 || !x || !y || !out)
+        return fail(KAJO_E_INVALID, "null argument");
+    int rc = bind(h);
+    if (rc || n == 0)
+        return rc;
+    DeviceBuffer dx, dy, dout;
+    HIP_TRY(dx.alloc((size_t)n * 4));
+    HIP_TRY(dy.alloc((size_t)n * 4));
+    HIP_TRY(dout.alloc((size_t)n * 4));
+    HIP_TRY(hipMemcpyAsync(dx.p, x, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(dy.p, y, (size_t)n * 4, hipMemcpyHostToDevice, h->stream));
+    hipError_t le = (hipError_t)kajo_kat_math_launch(fn, n, dx.p, dy.p, dout.p, h->stream);
+    if (le != hipSuccess)
+        return failHip(le, "kat math launch");
+    HIP_TRY(hipMemcpyAsync(out, dout.p, (size_t)n * 4, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return KAJO_OK;
 }
 

@@ -80,7 +80,7 @@ def cpu_baseline(scene, W, H):
     snapshot, else this repo's scalar port; on a bounded sample of the same frame."""
     from oraclelib import OracleLib, available
 
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     if available("ref"):
         kind, h = "reference", OracleLib("ref").create(scene)
     else:

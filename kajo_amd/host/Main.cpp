@@ -12,7 +12,6 @@
 #include "HipScheduler.h"
 #include "Image.h"
 #include "Preview.h"
-#include "scene/Parser.h"
 #include "scene/Scene.h"
 
 int main(int argc, char** argv)

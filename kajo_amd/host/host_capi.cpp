@@ -4,7 +4,6 @@
 #include <string>
 
 #include "kajo_scene.h"
-#include "scene/Parser.h"
 #include "scene/Scene.h"
 
 namespace

@@ -5,6 +5,7 @@
 #ifndef KAJO_HOST_SCENE_H
 #define KAJO_HOST_SCENE_H
 
+#include <string>
 #include <vector>
 
 namespace scene
@@ -68,6 +69,15 @@ public:
 
 // The test scene the reference builds when started without a scene file (renderer/Main.cpp:13-95).
 void buildTestScene(Scene& scene);
+
+// Loader for Kajo's JSON scene dialect (scene::Parser::load in the reference, scene/Parser.h:12-16);
+// implemented in scene/SceneLoader.cpp.
+class Parser
+{
+public:
+    static bool load(Scene& scene, const std::string& fileName, float aspectRatio);
+    static bool loadFromString(Scene& scene, const std::string& text, float aspectRatio);
+};
 
 } // namespace scene
 

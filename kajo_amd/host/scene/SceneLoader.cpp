@@ -1,4 +1,4 @@
-// scene/Parser.cpp -- loader for Kajo's JSON scene dialect.
+// scene/SceneLoader.cpp -- loader for Kajo's JSON scene dialect (scene::Parser).
 //
 // Behaviour follows the reference's scene::Parser (scene/Parser.cpp:14-232) so that the same files
 // give the same scene::Scene:
@@ -14,7 +14,6 @@
 //   * objects need a "type" ("sphere" | "plane"); material keys are optional (:168-211).
 // The matrix helpers restate glm 0.9.3.4's lookAt / translate / scale / rotate / perspective
 // (third_party/glm/glm/gtc/matrix_transform.inl:32-89,223-245,383-409) in float.
-#include "Parser.h"
 
 #include <cmath>
 #include <cstdlib>

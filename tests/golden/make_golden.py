@@ -64,7 +64,7 @@ def main():
     # ---- (1) parsed scenes -------------------------------------------------------------
     scenes = {}
     # the reference's own scene files, and this repo's scene files (kajo_amd/data) parsed BY THE
-    # REFERENCE'S PARSER: the expected output of the host-side loader (kajo_amd/host/scene/Parser.cpp)
+    # REFERENCE'S PARSER: the expected output of the host-side loader (kajo_amd/host/scene/SceneLoader.cpp)
     own = os.path.join(ROOT, "kajo_amd", "data")
     cases = [("spheres_a1", os.path.join(REF, "data/spheres.json"), 1.0),
              ("spheres_a169", os.path.join(REF, "data/spheres.json"), 1920.0 / 1080.0),

@@ -1,4 +1,4 @@
-"""The host-side scene loader (kajo_amd/host/scene/Parser.cpp) against the
+"""The host-side scene loader (kajo_amd/host/scene/SceneLoader.cpp) against the
 reference's own parser: tests/golden/scenes.npz holds what scene::Parser::load produced for the
 same files (both the -O2 and the fast-math build of the reference)."""
 import ctypes as C

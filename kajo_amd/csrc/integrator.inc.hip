@@ -294,21 +294,29 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
 
     const int np = sc.nPlanes;
 #if !KAJO_STRICT
+    // FAST selection arithmetic. On gfx950 compares, selects and min/max issue at half the rate of
+    // FMA/ADD/MUL/integer add (tools/valu_rate.hip), so the closest-hit bookkeeping is kept to one compare
+    // and two selects per primitive: for t >= 0 the bit pattern of a float orders like the float, while
+    // negative values and NaNs are patterns above +inf -- `bits(t) <= bits(tMax)` is "0 <= t <= tMax, not
+    // NaN" in one unsigned compare. The running index lives in a VGPR (an SGPR source operand halves the
+    // issue rate as well).
+    uint32_t kMax = 0x7f800000u; // +inf
+    uint32_t idV = 1;
+    asm volatile("" : "+v"(idV));
     if (sc.planesRigid) {
         // |det - 1| <= 2^-20 for every plane: t * det is t to within its own rounding, and the
         // second sign test repeats the first
-#ifdef KAJO_UNROLL
-#pragma unroll KAJO_UNROLL
-#endif
         for (int i = 0; i < np; i++) {
             const DFloat4 r = lds.planeRow[i];
             float denom = r.x * d.x + r.y * d.y + r.z * d.z;
             float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w;
-            float t = -oy * __builtin_amdgcn_rcpf(denom);
-            bool ok = !(__builtin_fabsf(denom) < kFltEpsilon) && !(t < 0.0f) && !(t > tMax);
-            tMax = ok ? t : tMax;
-            best = ok ? i + 1 : best;
+            const uint32_t kt = __builtin_bit_cast(uint32_t, -oy * __builtin_amdgcn_rcpf(denom));
+            bool ok = !(__builtin_fabsf(denom) < kFltEpsilon) && kt <= kMax;
+            kMax = ok ? kt : kMax;
+            best = ok ? (int)idV : best;
+            idV += 1;
         }
+        tMax = __builtin_bit_cast(float, kMax);
     } else
 #endif
     for (int i = 0; i < np; i++) { // Raytracer.cpp:74-98; only row y of the inverse matters
@@ -336,11 +344,15 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     }
 #if !KAJO_STRICT
     if (sc.allTranslated) {
-        // every sphere is (centre, radius): a = d.d is one value per ray; the two roots are
-        // (-h -+ sqrt(h^2 - a c)) / a
-#ifdef KAJO_UNROLL
-#pragma unroll KAJO_UNROLL
-#endif
+        // every sphere is (centre, radius): a = d.d is one value per ray and the two roots are
+        // (-h -+ sqrt(h^2 - a c)) / a. The walk compares a * t (the division is done once, for the winner);
+        // the smaller non-negative root is the smaller bit pattern of the two (see above: a negative root and
+        // the NaN of a negative discriminant sort above every acceptable value), so "no root, both behind,
+        // beyond the closest so far" is again one unsigned compare.
+        const float tPlane = tMax;
+        kMax = __builtin_bit_cast(uint32_t, tMax * aT);
+        idV = (uint32_t)np + 1;
+        asm volatile("" : "+v"(idV));
         for (int i = 0; i < ns; i++) {
             const DFloat4 s = lds.sphereHot[i];
             F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
@@ -348,14 +360,15 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
             float c = dot(o, o) - s.w;
             float discr = h * h - aT * c;
             float sq = __builtin_amdgcn_sqrtf(discr);
-            float lo = (-h - sq) * iaT, hi = (sq - h) * iaT;
-            float th = (lo < 0.0f) ? hi : lo;
-            bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(th > tMax);
-            tMax = ok ? th : tMax;
-            best = ok ? np + 1 + i : best;
-            bestT0 = ok ? th : bestT0;
+            const uint32_t klo = __builtin_bit_cast(uint32_t, -h - sq), khi = __builtin_bit_cast(uint32_t, sq - h);
+            const uint32_t kth = klo < khi ? klo : khi;
+            bool ok = kth <= kMax;
+            kMax = ok ? kth : kMax;
+            best = ok ? (int)idV : best;
+            idV += 1;
         }
-        return Hit{best, tMax, bestT0};
+        tMax = best > np ? __builtin_bit_cast(float, kMax) * iaT : tPlane;
+        return Hit{best, tMax, tMax};
     }
 #endif
     for (int i = 0; i < ns; i++) { // Raytracer.cpp:21-72

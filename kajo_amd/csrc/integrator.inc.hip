@@ -76,6 +76,14 @@ KDEV float kpow(float x, float y)
 }
 #endif
 
+// max(0, x) for an x that cannot exceed 1 (cosines of unit vectors, 1 - u, 1 - x^2): FAST folds it into the
+// clamp modifier of the instruction that produces x (v_max_f32 issues at half rate on gfx950)
+#if KAJO_STRICT
+KDEV float kmax0(float x) { return fmaxf(0.0f, x); }
+#else
+KDEV float kmax0(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
+#endif
+
 KDEV F3 normalize(F3 a)
 {
     float sqr = a.x * a.x + a.y * a.y + a.z * a.z;
@@ -444,7 +452,7 @@ KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
 #endif
     }
     if (kind == 1) { // BSDF.cpp:62-67
-        float cosA = fmaxf(0.0f, dot(R, dir));
+        float cosA = kmax0(dot(R, dir));
 #if KAJO_STRICT
         float s = (float)((double)(exponent + 1) / (2 * kPi));
 #else
@@ -452,7 +460,7 @@ KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
 #endif
         return (s * color) * kpow(cosA, exponent);
     }
-    float cosA = fmaxf(0.0f, dot(dir, N)); // BSDF.cpp:87-91
+    float cosA = kmax0(dot(dir, N)); // BSDF.cpp:87-91
     return f3(kdiv(color.x, cosA), kdiv(color.y, cosA), kdiv(color.z, cosA));
 }
 
@@ -467,7 +475,7 @@ KDEV float bsdfProbability(int kind, float exponent, F3 R, F3 N, F3 dir)
 #endif
     }
     if (kind == 1) { // BSDF.cpp:69-74
-        float cosA = fmaxf(0.0f, dot(R, dir));
+        float cosA = kmax0(dot(R, dir));
 #if KAJO_STRICT
         return (float)((double)(exponent + 1) / (2 * kPi) * (double)kpow(cosA, exponent));
 #else
@@ -499,7 +507,7 @@ KDEV F3 bsdfGenerate(int kind, float exponent, F3 R, F3 N, F3 tg, F3 bn, Rng& rn
 #else
         float x = r * __builtin_amdgcn_cosf(v); // v_cos_f32 takes revolutions: cos(2 pi v)
         float y = r * __builtin_amdgcn_sinf(v);
-        float z = ksqrt(fmaxf(0.0f, 1.0f - u));
+        float z = ksqrt(kmax0(1.0f - u));
         pdf = z * kInvPiF;
 #endif
         return tg * x + bn * y + N * z;
@@ -514,7 +522,7 @@ KDEV F3 bsdfGenerate(int kind, float exponent, F3 R, F3 N, F3 tg, F3 bn, Rng& rn
     // cos(acos(c)) = c and sin(acos(c)) = sqrt(1 - c^2): no inverse trigonometry needed
     float lg = __builtin_amdgcn_logf(u);
     float ca = __builtin_amdgcn_exp2f(lg * krcp(exponent + 1));
-    float sa = ksqrt(fmaxf(0.0f, 1.0f - ca * ca));
+    float sa = ksqrt(kmax0(1.0f - ca * ca));
     s = f3(sa * __builtin_amdgcn_cosf(v), sa * __builtin_amdgcn_sinf(v), ca);
     pdf = (exponent + 1) * kInv2PiF * kpow(ca, exponent);
 #endif
@@ -551,7 +559,7 @@ KDEV float solidAngle(F3 centre, float radius, F3 P)
     // 1 - cos(asin x) = x^2 / (1 + sqrt(1 - x^2)): same value without the cancellation
     float x = radius * krcp(dist);
     float x2 = x * x;
-    float v = 6.28318530717958647692f * x2 * krcp(1.0f + ksqrt(fmaxf(0.0f, 1.0f - x2)));
+    float v = 6.28318530717958647692f * x2 * krcp(1.0f + ksqrt(kmax0(1.0f - x2)));
     return dist < radius ? 12.56637061435917295385f : v;
 #endif
 }
@@ -565,7 +573,7 @@ KDEV float lightPdf(const DSphereCold& lc, F3 P)
     float d2 = dot(v, v);
     float r2 = lc.radius * lc.radius;
     float x2 = r2 * __builtin_amdgcn_rcpf(d2);
-    float p = (1.0f + __builtin_amdgcn_sqrtf(fmaxf(0.0f, 1.0f - x2))) * d2 * lc.invTwoPiR2;
+    float p = (1.0f + __builtin_amdgcn_sqrtf(kmax0(1.0f - x2))) * d2 * lc.invTwoPiR2;
     return d2 < r2 ? 0.07957747154594767f : p; // inside the light: 1 / (4 pi)
 }
 #endif
@@ -1041,7 +1049,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 const float pb = bsdfProbability(vKind, vExp, vR, vN, l);
                 // A light at or below the horizon contributes max(0, n.l) = 0 whatever the shadow ray
                 // finds (the sum stays as it is: x + (+-0) == x), so that walk is skipped as well.
-                const float cosL = fmaxf(0.0f, dot(vN, l));
+                const float cosL = kmax0(dot(vN, l));
                 if (pl == 0.0f || pb == 0.0f || cosL == 0.0f) {
                     lightK++;
                     continue;
@@ -1074,7 +1082,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     pathDone = true;
                 } else {
                     pendF = bsdfEvaluate(vKind, vColor, vExp, vR, vN, nd);
-                    pendCos = fmaxf(0.0f, dot(vN, nd));
+                    pendCos = kmax0(dot(vN, nd));
                     pendP = p;
                     pendBsdf = true;
                     pendT = T;

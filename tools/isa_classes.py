@@ -23,13 +23,10 @@ def classify(line):
         srcs = args[1:]
         if any(re.fullmatch(r"-?\|?s\d+\|?|s\[\d+:\d+\]|vcc|exec|m0|vcc_lo|vcc_hi|exec_lo|exec_hi", a) for a in srcs):
             return "slow(sgpr)", op
-        regs = [int(m.group(1)) for a in srcs for m in [re.fullmatch(r"-?\|?v(\d+)\|?( clamp)?", a.split(" ")[0] if " " in a else a)] if m]
-        if op == "v_fmac_f32":  # destination is also the addend
-            m = re.fullmatch(r"v(\d+)", args[0])
-            if m:
-                regs.append(int(m.group(1)))
-        banks = collections.Counter(r % 4 for r in set(regs))
-        if any(c > 1 for c in banks.values()):
+        # measured: v_fmac with src0 and src1 in one bank, v_fma reading its own destination with src1 and src2 in
+        # one bank are slow; other same-bank pairs are not
+        regs = [int(m.group(1)) if m else None for a in srcs for m in [re.fullmatch(r"-?\|?v(\d+)\|?", a.replace(" clamp", ""))]]
+        if op == "v_fmac_f32" and len(regs) >= 2 and None not in regs[:2] and regs[0] % 4 == regs[1] % 4 and regs[0] != regs[1]:
             return "slow(bank)", op
         return "fast", op
     return "slow", op

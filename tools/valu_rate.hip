@@ -112,6 +112,16 @@
 #define I_SAND(d) "s_and_b64 s[22:23], s[22:23], exec\n"
 #define I_SADD(d) "s_add_u32 s21, s21, 1\n"
 #define I_SMOV(d) "s_mov_b32 s21, 1\n"
+
+#define I_MUL_SAME(d) "v_mul_f32_e32 v" #d ", v16, v20\n"
+#define I_ADD_SAME(d) "v_add_f32_e32 v" #d ", v16, v20\n"
+#define I_FMAC_S01(d) "v_fmac_f32_e32 v" #d ", v16, v20\n"
+#define I_FMAC_DS0(d) "v_fmac_f32_e32 v" #d ", v16, v17\n"
+#define I_FMAC_DS1(d) "v_fmac_f32_e32 v" #d ", v17, v16\n"
+#define I_FMA_S02(d) "v_fma_f32 v" #d ", v16, v17, v20\n"
+#define I_FMA_S01(d) "v_fma_f32 v" #d ", v16, v20, v17\n"
+#define I_FMA_S12(d) "v_fma_f32 v" #d ", v17, v16, v20\n"
+#define I_CND_SAME(d) "v_cmp_gt_f32_e32 vcc, v16, v" #d "\n v_cndmask_b32_e32 v" #d ", v16, v20, vcc\n"
 // one transcendental among seven FMAs / one per three
 #define I_MIX_RCP8 "v_rcp_f32_e32 v22, v16\n" I_FMA_FREE(23) I_FMA_FREE(26) I_FMA_FREE(27) I_FMA_FREE(30) I_FMA_FREE(31) I_FMA_FREE(34) I_FMA_FREE(35)
 #define I_MIX_RCP4 "v_rcp_f32_e32 v22, v16\n" I_FMA_FREE(23) I_FMA_FREE(26) I_FMA_FREE(27) "v_rcp_f32_e32 v30, v16\n" I_FMA_FREE(31) I_FMA_FREE(34) I_FMA_FREE(35)
@@ -197,6 +207,14 @@
     K(sand, "s_and_b64 (chain)", X4(D8(I_SAND)))                                                                       \
     K(sadd, "s_add_u32 (chain)", X4(D8(I_SADD)))                                                                       \
     K(smov, "s_mov_b32", X4(D8(I_SMOV)))                                                                               \
+    K(bk_mul01, "v_mul src0,src1 same bank", X4(D8(I_MUL_SAME)))                                                       \
+    K(bk_add01, "v_add src0,src1 same bank", X4(D8(I_ADD_SAME)))                                                       \
+    K(bk_fmac01, "v_fmac src0,src1 same bank", X4(D8(I_FMAC_S01)))                                                     \
+    K(bk_fmacd0, "v_fmac dst,src0 same bank", X4(Z8(I_FMAC_DS0)))                                                      \
+    K(bk_fmacd1, "v_fmac dst,src1 same bank", X4(Z8(I_FMAC_DS1)))                                                      \
+    K(bk_fma02, "v_fma src0,src2 same bank", X4(D8(I_FMA_S02)))                                                        \
+    K(bk_fma01, "v_fma src0,src1 same bank", X4(D8(I_FMA_S01)))                                                        \
+    K(bk_fma12, "v_fma src1,src2 same bank", X4(D8(I_FMA_S12)))                                                        \
     K(fma_salu, "v_fma + 1 SALU (32 VALU)", X4(D8(I_FMA_SALU)))                                                        \
     K(fma_salu2, "v_fma + 2 SALU (32 VALU)", X4(D8(I_FMA_SALU2)))                                                      \
     K(mix_rcp8, "1 rcp + 7 fma", X4(I_MIX_RCP8))                                                                       \

@@ -75,6 +75,12 @@ KDEV float kpow(float x, float y)
     return y == 0.0f ? 1.0f : r;
 }
 #endif
+// the Phong lobe: its exponent is never zero (a zero exponent selects the ideal reflector, Shader.cpp:155-158)
+#if KAJO_STRICT
+KDEV float kpowPhong(float x, float y) { return kajo_powf(x, y); }
+#else
+KDEV float kpowPhong(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#endif
 
 // max(0, x) for an x that cannot exceed 1 (cosines of unit vectors, 1 - u, 1 - x^2): FAST folds it into the
 // clamp modifier of the instruction that produces x (v_max_f32 issues at half rate on gfx950)
@@ -485,12 +491,39 @@ KDEV float bsdfProbability(int kind, float exponent, F3 R, F3 N, F3 dir)
     return 0.0f; // BSDF.cpp:93-96
 }
 
+// evaluate() and probability() toward the same direction (Shader.cpp:74-80): the Phong power is formed once.
+// A zero pdf (always for the reflector) discards the sample, so no value is computed for it.
+KDEV F3 bsdfEvaluateWithPdf(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir, float& pdf)
+{
+    if (kind == 1) { // BSDF.cpp:62-74
+        const float pw = kpowPhong(kmax0(dot(R, dir)), exponent);
+#if KAJO_STRICT
+        pdf = (float)((double)(exponent + 1) / (2 * kPi) * (double)pw);
+        const float s = (float)((double)(exponent + 1) / (2 * kPi));
+#else
+        const float s = (exponent + 1) * kInv2PiF;
+        pdf = s * pw;
+#endif
+        return (s * color) * pw;
+    }
+    if (kind == 0) {
+        pdf = bsdfProbability(0, exponent, R, N, dir);
+        return bsdfEvaluate(0, color, exponent, R, N, dir);
+    }
+    pdf = 0.0f;
+    return f3(0.0f, 0.0f, 0.0f);
+}
+
 // generateSample of Lambert / Phong / reflector (BSDF.cpp:20-28,48-60,82-85 with
 // Random.cpp:77-102). tg/bn only read for Lambert.
-KDEV F3 bsdfGenerate(int kind, float exponent, F3 R, F3 N, F3 tg, F3 bn, Rng& rng, float& pdf)
+// `value` = evaluate() toward the generated direction (Shader.cpp:203). FAST forms the Phong value from the
+// power the pdf already needed: cos(angle to R) of the generated direction IS the sampled cosine, and
+// log2 of it is the exponent argument that produced it.
+KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 bn, Rng& rng, float& pdf, F3& value)
 {
     if (kind == 2) {
         pdf = 1.0f;
+        value = bsdfEvaluate(2, color, exponent, R, N, R);
         return R;
     }
     rngStep(rng);
@@ -510,6 +543,7 @@ KDEV F3 bsdfGenerate(int kind, float exponent, F3 R, F3 N, F3 tg, F3 bn, Rng& rn
         float z = ksqrt(kmax0(1.0f - u));
         pdf = z * kInvPiF;
 #endif
+        value = bsdfEvaluate(0, color, exponent, R, N, N);
         return tg * x + bn * y + N * z;
     }
     F3 s;
@@ -520,16 +554,23 @@ KDEV F3 bsdfGenerate(int kind, float exponent, F3 R, F3 N, F3 tg, F3 bn, Rng& rn
     pdf = (float)((double)(exponent + 1) / (2 * kPi) * (double)kajo_powf(kajo_cosf(a), exponent));
 #else
     // cos(acos(c)) = c and sin(acos(c)) = sqrt(1 - c^2): no inverse trigonometry needed
-    float lg = __builtin_amdgcn_logf(u);
-    float ca = __builtin_amdgcn_exp2f(lg * krcp(exponent + 1));
+    const float lca = __builtin_amdgcn_logf(u) * krcp(exponent + 1); // log2 of the sampled cosine
+    float ca = __builtin_amdgcn_exp2f(lca);
     float sa = ksqrt(kmax0(1.0f - ca * ca));
     s = f3(sa * __builtin_amdgcn_cosf(v), sa * __builtin_amdgcn_sinf(v), ca);
-    pdf = (exponent + 1) * kInv2PiF * kpow(ca, exponent);
+    const float pw = __builtin_amdgcn_exp2f(exponent * lca); // ca ^ exponent
+    const float sc = (exponent + 1) * kInv2PiF;
+    pdf = sc * pw;
+    value = (sc * color) * pw;
 #endif
     F3 uu = normalize(cross(f3(0.0f, 0.0f, 1.0f), R));
     F3 vv = cross(uu, R);
-    return f3(uu.x * s.x + vv.x * s.y + R.x * s.z, uu.y * s.x + vv.y * s.y + R.y * s.z,
-              uu.z * s.x + vv.z * s.y + R.z * s.z);
+    const F3 nd = f3(uu.x * s.x + vv.x * s.y + R.x * s.z, uu.y * s.x + vv.y * s.y + R.y * s.z,
+                     uu.z * s.x + vv.z * s.y + R.z * s.z);
+#if KAJO_STRICT
+    value = bsdfEvaluate(1, color, exponent, R, N, nd);
+#endif
+    return nd;
 }
 
 // IdealTransmissionBSDF::generateSample, BSDF.cpp:105-124 + glm::refract
@@ -1046,7 +1087,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // The reference traces first and asks the BSDF afterwards; a zero BSDF pdf (always for
                 // the reflector, outside the lobe for Phong) discards the sample either way, so the
                 // trace is skipped for it.
-                const float pb = bsdfProbability(vKind, vExp, vR, vN, l);
+                float pb;
+                const F3 fl = bsdfEvaluateWithPdf(vKind, vColor, vExp, vR, vN, l, pb);
                 // A light at or below the horizon contributes max(0, n.l) = 0 whatever the shadow ray
                 // finds (the sum stays as it is: x + (+-0) == x), so that walk is skipped as well.
                 const float cosL = kmax0(dot(vN, l));
@@ -1055,7 +1097,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     continue;
                 }
                 const F3 Le = ld3(lds.material[np + si].emission);
-                pendContrib = ((krcp(pb + pl) * bsdfEvaluate(vKind, vColor, vExp, vR, vN, l)) * cosL) * Le;
+                pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
                 O = vP + l * kEps;
                 d = l;
                 mode = MODE_SHADOW;
@@ -1076,12 +1118,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     }
                 }
                 float p;
-                const F3 nd = bsdfGenerate(vKind, vExp, vR, vN, tg, bn, rng, p);
+                F3 fd;
+                const F3 nd = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
                 L = L + T * (vS * (vE + vLd));
                 if (p == 0.0f) {
                     pathDone = true;
                 } else {
-                    pendF = bsdfEvaluate(vKind, vColor, vExp, vR, vN, nd);
+                    pendF = fd;
                     pendCos = kmax0(dot(vN, nd));
                     pendP = p;
                     pendBsdf = true;

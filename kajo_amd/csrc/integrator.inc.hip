@@ -563,8 +563,15 @@ KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 b
     pdf = sc * pw;
     value = (sc * color) * pw;
 #endif
+#if KAJO_STRICT
     F3 uu = normalize(cross(f3(0.0f, 0.0f, 1.0f), R));
     F3 vv = cross(uu, R);
+#else
+    // cross((0,0,1), R) = (-R.y, R.x, 0), written out: the products with the zeros are not folded otherwise
+    const float iu = __builtin_amdgcn_rsqf(R.x * R.x + R.y * R.y);
+    F3 uu = f3(-R.y * iu, R.x * iu, 0.0f);
+    F3 vv = f3(uu.y * R.z, -(uu.x * R.z), uu.x * R.y - R.x * uu.y);
+#endif
     const F3 nd = f3(uu.x * s.x + vv.x * s.y + R.x * s.z, uu.y * s.x + vv.y * s.y + R.y * s.z,
                      uu.z * s.x + vv.z * s.y + R.z * s.z);
 #if KAJO_STRICT

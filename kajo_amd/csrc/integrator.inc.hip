@@ -57,6 +57,12 @@ KDEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 KDEV F3 cross(F3 a, F3 b) { return f3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 KDEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 
+#if defined(KAJO_X_IEEE) && !KAJO_STRICT
+// experiment (tools/flip_experiment.sh): FAST structure with correctly rounded divide / square root
+#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
+#define __builtin_amdgcn_sqrtf(x) __builtin_sqrtf(x)
+#define __builtin_amdgcn_rsqf(x) (1.0f / __builtin_sqrtf(x))
+#endif
 // ---- numerics policy ------------------------------------------------------------------
 #if KAJO_STRICT
 KDEV float kdiv(float a, float b) { return a / b; }

@@ -653,6 +653,8 @@ struct Oracle
             if (ctr)
                 ctr->vertices++;
             logEvent(1, (float)sp.id, (float)depth, sp.t);
+            logEvent(5, sp.position.x, sp.position.y, sp.position.z);
+            logEvent(6, sp.normal.x, sp.normal.y, sp.normal.z);
             const Mat& m = material(sp.id);
             V3 E = collectEmission ? m.emission : v3(0, 0, 0); // :121
 
@@ -682,6 +684,8 @@ struct Oracle
                 float pdf;
                 V3 d = bsdfGenerate<M>(f, sp, rng, &pdf);
                 V3 o = sp.position + d * kSurfaceEpsilon;
+                logEvent(8, o.x, o.y, o.z);
+                logEvent(9, d.x, d.y, d.z);
                 Hit next = trace(o, d, ctr);
                 V3 w = (1 / pc * 1 / pt * bsdfEvaluate<M>(f, sp, d)) * std::fabs(dot(sp.normal, d));
                 L = L + T * (w * E);
@@ -718,6 +722,7 @@ struct Oracle
                 if (pl == 0.0f)
                     continue;
                 V3 so = sp.position + l * kSurfaceEpsilon;
+                logEvent(7, l.x, l.y, l.z);
                 Hit sh = trace(so, l, ctr);
                 if (sh.id != 1 + np + i)
                     continue;
@@ -736,6 +741,8 @@ struct Oracle
                 break;
             }
             V3 o = sp.position + d * kSurfaceEpsilon; // :197-200
+            logEvent(8, o.x, o.y, o.z);
+            logEvent(9, d.x, d.y, d.z);
             Hit next = trace(o, d, ctr);
 
             // calculateLightProbabilities, :88-111 -- every term re-traces (o, d); only the
@@ -1119,9 +1126,38 @@ void koracle_strictmath(int fn, int n, const float* x, const float* y, float* ou
     }
 }
 
+// Camera ray of ONE path (Renderer.cpp:51-64 under the stream protocol) and the generator state after its
+// jitter draw: what kajo_hip_kat_shade / koracle_shade take, so that single paths of a frame can be replayed.
+int koracle_camera_ray(void* hh, int W, int Hh, int S, int pass, uint64_t seed, int x, int y, int sample, float* ray6,
+                       uint64_t* state2)
+{
+    Handle* H = static_cast<Handle*>(hh);
+    const Oracle& o = *H->o;
+    Oracle::FrameConsts c = Oracle::frameConsts(W, Hh, S);
+    Rng rng;
+    uint64_t st[2];
+    kajo_stream_state(seed, (uint32_t)pass, (uint32_t)sample, (uint32_t)(y * W + x), st);
+    rng.lo = st[0];
+    rng.hi = st[1];
+    float g[4];
+    rng.generate(g);
+    const int sampleX = sample % c.n, sampleY = sample / c.n;
+    float offX = g[0] * .5f + .5f;
+    float offY = g[1] * .5f + .5f;
+    float sx = x * c.pixelWidth + sampleX * c.sampleWidth + offX * c.sampleWidth;
+    float sy = (c.H - y) * c.pixelHeight + sampleY * c.sampleHeight + offY * c.sampleHeight;
+    V3 direction = normalize(o.p1 + (o.p2 - o.p1) * sx + (o.p3 - o.p1) * sy - o.origin);
+    st3(ray6, 0, o.origin);
+    st3(ray6, 1, direction);
+    state2[0] = rng.lo;
+    state2[1] = rng.hi;
+    return 0;
+}
+
 // Event log of ONE camera path (pixel x,y; sample index; pass): records of 4 floats
 // (code, a, b, c): 1 = vertex (id, depth, t), 2 = lobe (kind, s), 3 = light sample kept (pb, pl, Ld.x),
-// 4 = BSDF extension (p, pL, wb.x). Returns the number of floats written (<= cap); rgb gets the path radiance.
+// 4 = BSDF extension (p, pL, wb.x), 5 / 6 = vertex position / normal, 7 = light sample direction, 8 / 9 = origin /
+// direction of the next segment. Returns the number of floats written (<= cap); rgb gets the path radiance.
 int koracle_debug_path(void* hh, int W, int Hh, int S, int pass, uint64_t seed, int depthLimit, int x, int y,
                        int sample, float* out, int cap, float* rgb)
 {

@@ -122,6 +122,35 @@ def parity_leg(scene, W, H, renderer_factory):
             "px_off_by_more_than_1e-3": int((np.abs(cl).max(-1) > 1e-3).sum()), "nonfinite_px": int((~m).sum() // 3)}
 
 
+def strict_leg(scene, W, H, local_rank):
+    """The STRICT kernels on the same frame: the mode whose radiance buffer is bit-identical to the CPU oracle (and to
+    the reference's -O2 build up to its own float reassociation): its rate, and the comparison on the parity frame."""
+    from kajo_amd.renderer import HipRenderer
+    from oraclelib import OracleLib
+
+    r = HipRenderer(scene, W, H, spp=SPP, depth_limit=DEPTH, seed=SEED, strict=True, device=local_rank)
+    r.render(PASSES).wait()
+    c0 = r.counters()
+    t0 = time.perf_counter()
+    r.render(PASSES).wait()
+    dt = time.perf_counter() - t0
+    c1 = r.counters()
+    r.close()
+    w, h = 256, 144
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    want = OracleLib("oracle").create(scene, 1).render(w, h, S=SPP, passes=PASSES, seed=SEED, depth_limit=DEPTH,
+                                                        threads=max(1, min(cores, 64)))
+    rs = HipRenderer(scene, w, h, spp=SPP, depth_limit=DEPTH, seed=SEED, strict=True, device=local_rank)
+    got = rs.render(PASSES).radiance()
+    rs.close()
+    same = (got.view(np.uint32) == want.view(np.uint32))[..., :3].all(-1)
+    cl = np.nan_to_num(np.clip(got[..., :3], 0, 1) - np.clip(want[..., :3], 0, 1)) / PASSES
+    return {"value": (c1["paths"] - c0["paths"]) / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3,
+            "kernel_ms_per_launch": (c1["kernelMs"] - c0["kernelMs"]) / max(c1["launches"] - c0["launches"], 1),
+            "parity": {"frame": "%dx%d, %d passes, vs oracle (strict math)" % (w, h, PASSES),
+                       "bit_identical_px": int(same.sum()), "px": int(same.size), "rmse_clamped01": float(np.sqrt(np.mean(cl ** 2)))}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -265,6 +294,9 @@ def main():
         out["cpu_baseline"] = cpu_baseline(scene, W, H)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         out["parity"] = parity_leg(scene, W, H, factory)
+        if not args.strict:
+            out["strict_mode"] = strict_leg(scene, W, H, local_rank)
+            out["strict_mode"]["speedup_vs_cpu_baseline"] = out["strict_mode"]["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -213,6 +213,16 @@ class Handle:
         return s, acc
 
 
+def camera_ray(handle, W, H, S, x, y, sample, npass=1, seed=236367):
+    """Oracle only: camera ray (origin, direction) of one path and the generator state after its jitter draw --
+    what shade() / kajo_hip_kat_shade take, so that the paths of a frame can be replayed one by one."""
+    ray = np.zeros(6, np.float32)
+    state = np.zeros(2, np.uint64)
+    handle.L.lib.koracle_camera_ray(handle.h, C.c_int(W), C.c_int(H), C.c_int(S), C.c_int(npass), C.c_uint64(seed), C.c_int(x),
+                                    C.c_int(y), C.c_int(sample), _p(ray), _p(state))
+    return ray[:3].copy(), ray[3:].copy(), state
+
+
 def debug_path(handle, W, H, S, x, y, sample, npass=1, seed=236367, depth_limit=8):
     """Oracle only: event log of one camera path (see koracle_debug_path)."""
     out = np.zeros(4096, np.float32)

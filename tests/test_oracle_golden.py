@@ -14,7 +14,7 @@ import json
 import numpy as np
 import pytest
 
-from oraclelib import OracleLib, available
+from oraclelib import OracleLib, available, camera_ray, debug_path
 
 pytestmark = pytest.mark.skipif(not available("oracle"), reason="oracle/libkajo_oracle.so not built (run __graft_entry__.build())")
 
@@ -203,3 +203,23 @@ def test_counters(O, scenes):
     # SURVEY.md section 8d anchor: T_min = 1.887 traversals per path on spheres.json 16:9
     assert 1.7 < trav / paths < 2.1
     assert 1.3 < vert / paths < 1.8
+
+
+def test_single_path_replay(O, scenes):
+    """The replay hooks used for parity forensics (tools/flip_trace.py): the 25 camera rays of a pixel, shaded one by
+    one from their exported generator states, sum to exactly the pixel the frame renderer produced; the event log of a
+    path reports the radiance shade() returns for it."""
+    h = O.create(scenes["spheres_a169"])
+    W, H, S = 48, 27, 32
+    frame = h.render(W, H, S=S, passes=1, seed=236367, depth_limit=8, threads=2)
+    for (x, y) in ((0, 0), (17, 20), (47, 26), (30, 9)):
+        rays = [camera_ray(h, W, H, S, x, y, s) for s in range(25)]
+        rgb, _ = h.shade(np.array([r[0] for r in rays]), np.array([r[1] for r in rays]), np.array([r[2] for r in rays]), depth_limit=8)
+        acc = np.zeros(3, np.float32)
+        for k in range(25):  # Renderer.cpp:66 sums in sample order
+            acc = (acc + rgb[k]).astype(np.float32)
+        want = (acc / np.float32(S)).astype(np.float32)
+        assert np.array_equal(want.view(np.uint32), frame[y, x, :3].view(np.uint32)), (x, y, want, frame[y, x])
+        log, one = debug_path(h, W, H, S, x, y, 7)
+        assert np.array_equal(one.view(np.uint32), rgb[7].view(np.uint32))
+        assert log.shape[1] == 4 and int(log[0, 0]) in (1, 0) or len(log) == 0

@@ -12,7 +12,7 @@ import numpy as np
 import torch  # noqa: F401
 from kajo_amd.renderer import HipRenderer
 from kajo_amd.scene import Scene
-from oraclelib import OracleLib, debug_path, _p
+from oraclelib import OracleLib, debug_path, camera_ray, _p
 
 W, H, S, PASSES, SEED = 256, 144, 32, 16, 0o715517
 top = int(sys.argv[1]) if len(sys.argv) > 1 else 12
@@ -32,8 +32,8 @@ def camera_rays(x, y):
     k = 0
     for p in range(1, PASSES + 1):
         for s in range(25):
-            orc.L.lib.koracle_camera_ray(orc.h, C.c_int(W), C.c_int(H), C.c_int(S), C.c_int(p), C.c_uint64(SEED), C.c_int(x),
-                                         C.c_int(y), C.c_int(s), _p(rays[k]), _p(states[k]))
+            o, d, st = camera_ray(orc, W, H, S, x, y, s, npass=p, seed=SEED)
+            rays[k, :3], rays[k, 3:], states[k] = o, d, st
             k += 1
     return rays, states
 

@@ -1132,22 +1132,22 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
                 float p;
                 F3 fd;
-                const F3 nd = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
+                d = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
                 L = L + T * (vS * (vE + vLd));
-                if (p == 0.0f) {
+                // The next segment's state is written unconditionally: a path that ends here (p == 0) re-initialises
+                // all of it when its lane starts the next camera path, and unconditional writes need no copies.
+                pendF = fd;
+                pendCos = kmax0(dot(vN, d));
+                pendP = p;
+                pendBsdf = true;
+                pendT = T;
+                T = T * (vS * ((krcp(0.0f + p) * pendF) * pendCos));
+                O = vP + d * kEps;
+                depth++;
+                if (p == 0.0f)
                     pathDone = true;
-                } else {
-                    pendF = fd;
-                    pendCos = kmax0(dot(vN, nd));
-                    pendP = p;
-                    pendBsdf = true;
-                    pendT = T;
-                    T = T * (vS * ((krcp(0.0f + p) * pendF) * pendCos));
-                    O = vP + nd * kEps;
-                    d = nd;
-                    depth++;
+                else
                     mode = MODE_EXTEND;
-                }
             }
         }
 

@@ -1093,7 +1093,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
                 const DSphereCold& lc = lds.sphereCold[si];
                 float pl;
-                const F3 l = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
+                // written straight into the ray: a discarded sample leaves d and O to the next light or to the BSDF sample
+                d = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
+                const F3 l = d;
 #if !KAJO_STRICT
                 pl = lightPdf(lc, vP);
 #endif
@@ -1105,14 +1107,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // A light at or below the horizon contributes max(0, n.l) = 0 whatever the shadow ray
                 // finds (the sum stays as it is: x + (+-0) == x), so that walk is skipped as well.
                 const float cosL = kmax0(dot(vN, l));
+                O = vP + l * kEps;
                 if (pl == 0.0f || pb == 0.0f || cosL == 0.0f) {
                     lightK++;
                     continue;
                 }
                 const F3 Le = ld3(lds.material[np + si].emission);
                 pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
-                O = vP + l * kEps;
-                d = l;
                 mode = MODE_SHADOW;
                 shadowRay = true;
                 break;

@@ -7,7 +7,7 @@
  * flipped branch changes a whole path, so "does the GPU integrator
  * take exactly the decisions the CPU integrator takes" is only testable when both sides
  * evaluate these five functions with the same arithmetic. This header is that arithmetic:
- * range reduction + truncated series in IEEE binary64 using only + - * / sqrt floor and
+ * range reduction + truncated series in IEEE binary64 using only + - * / fma sqrt floor and
  * integer bit moves, rounded once to binary32 at the end. Compiled with FP contraction off
  * it yields identical bits from g++ on x86-64 and from hipcc on gfx950; its error before
  * the final rounding is < 1e-11 relative, i.e. the float result equals the correctly rounded
@@ -28,6 +28,22 @@
 #define KSM_FN __host__ __device__ static inline
 #else
 #define KSM_FN static inline
+#endif
+
+/* One rounding per Horner step: fma is exactly specified, so x86-64 (vfmadd / glibc fma) and gfx950 (v_fma_f64)
+   still agree bit for bit, with half the operations of a separate multiply and add. */
+#if defined(__HIP_DEVICE_COMPILE__)
+/* v_fma_f64 with the coefficient as a scalar operand: left to itself the compiler picks the two-address v_fmac_f64 and
+   first moves every 64-bit coefficient into a VGPR pair (more moves than the fma saves, and spills) */
+KSM_FN double ksm_fma_coeff(double a, double b, double c)
+{
+    double r;
+    __asm__("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+    return r;
+}
+#define KSM_FMA(a, b, c) ksm_fma_coeff((a), (b), (c))
+#else
+#define KSM_FMA(a, b, c) __builtin_fma((a), (b), (c))
 #endif
 
 KSM_FN uint64_t ksm_bits(double d)
@@ -55,14 +71,14 @@ KSM_FN double ksm_sin_kernel(double r)
 {
     double z = r * r;
     double p = -0x1.2f49b46814157p-57;
-    p = p * z + 0x1.952c77030ad4ap-49;
-    p = p * z + -0x1.ae7f3e733b81fp-41;
-    p = p * z + 0x1.6124613a86d09p-33;
-    p = p * z + -0x1.ae64567f544e4p-26;
-    p = p * z + 0x1.71de3a556c734p-19;
-    p = p * z + -0x1.a01a01a01a01ap-13;
-    p = p * z + 0x1.1111111111111p-7;
-    p = p * z + -0x1.5555555555555p-3;
+    p = KSM_FMA(p, z, 0x1.952c77030ad4ap-49);
+    p = KSM_FMA(p, z, -0x1.ae7f3e733b81fp-41);
+    p = KSM_FMA(p, z, 0x1.6124613a86d09p-33);
+    p = KSM_FMA(p, z, -0x1.ae64567f544e4p-26);
+    p = KSM_FMA(p, z, 0x1.71de3a556c734p-19);
+    p = KSM_FMA(p, z, -0x1.a01a01a01a01ap-13);
+    p = KSM_FMA(p, z, 0x1.1111111111111p-7);
+    p = KSM_FMA(p, z, -0x1.5555555555555p-3);
     return r + r * (z * p);
 }
 
@@ -71,15 +87,15 @@ KSM_FN double ksm_cos_kernel(double r)
 {
     double z = r * r;
     double p = 0x1.e542ba4020225p-62;
-    p = p * z + -0x1.6827863b97d97p-53;
-    p = p * z + 0x1.ae7f3e733b81fp-45;
-    p = p * z + -0x1.93974a8c07c9dp-37;
-    p = p * z + 0x1.1eed8eff8d898p-29;
-    p = p * z + -0x1.27e4fb7789f5cp-22;
-    p = p * z + 0x1.a01a01a01a01ap-16;
-    p = p * z + -0x1.6c16c16c16c17p-10;
-    p = p * z + 0x1.5555555555555p-5;
-    p = p * z + -0x1.0000000000000p-1;
+    p = KSM_FMA(p, z, -0x1.6827863b97d97p-53);
+    p = KSM_FMA(p, z, 0x1.ae7f3e733b81fp-45);
+    p = KSM_FMA(p, z, -0x1.93974a8c07c9dp-37);
+    p = KSM_FMA(p, z, 0x1.1eed8eff8d898p-29);
+    p = KSM_FMA(p, z, -0x1.27e4fb7789f5cp-22);
+    p = KSM_FMA(p, z, 0x1.a01a01a01a01ap-16);
+    p = KSM_FMA(p, z, -0x1.6c16c16c16c17p-10);
+    p = KSM_FMA(p, z, 0x1.5555555555555p-5);
+    p = KSM_FMA(p, z, -0x1.0000000000000p-1);
     return 1.0 + z * p;
 }
 
@@ -123,22 +139,22 @@ KSM_FN double ksm_asin_kernel(double x)
 {
     double z = x * x;
     double p = 0x1.fcaf8fb6db6dbp-9;
-    p = p * z + 0x1.15ee9d45d1746p-8;
-    p = p * z + 0x1.31683bdef7bdfp-8;
-    p = p * z + 0x1.51ba308d3dcb1p-8;
-    p = p * z + 0x1.782dda12f684cp-8;
-    p = p * z + 0x1.a6863d70a3d71p-8;
-    p = p * z + 0x1.df3bd37a6f4dfp-8;
-    p = p * z + 0x1.12ef3cf3cf3cfp-7;
-    p = p * z + 0x1.3fde50d79435ep-7;
-    p = p * z + 0x1.7a87878787878p-7;
-    p = p * z + 0x1.c99999999999ap-7;
-    p = p * z + 0x1.1c4ec4ec4ec4fp-6;
-    p = p * z + 0x1.6e8ba2e8ba2e9p-6;
-    p = p * z + 0x1.f1c71c71c71c7p-6;
-    p = p * z + 0x1.6db6db6db6db7p-5;
-    p = p * z + 0x1.3333333333333p-4;
-    p = p * z + 0x1.5555555555555p-3;
+    p = KSM_FMA(p, z, 0x1.15ee9d45d1746p-8);
+    p = KSM_FMA(p, z, 0x1.31683bdef7bdfp-8);
+    p = KSM_FMA(p, z, 0x1.51ba308d3dcb1p-8);
+    p = KSM_FMA(p, z, 0x1.782dda12f684cp-8);
+    p = KSM_FMA(p, z, 0x1.a6863d70a3d71p-8);
+    p = KSM_FMA(p, z, 0x1.df3bd37a6f4dfp-8);
+    p = KSM_FMA(p, z, 0x1.12ef3cf3cf3cfp-7);
+    p = KSM_FMA(p, z, 0x1.3fde50d79435ep-7);
+    p = KSM_FMA(p, z, 0x1.7a87878787878p-7);
+    p = KSM_FMA(p, z, 0x1.c99999999999ap-7);
+    p = KSM_FMA(p, z, 0x1.1c4ec4ec4ec4fp-6);
+    p = KSM_FMA(p, z, 0x1.6e8ba2e8ba2e9p-6);
+    p = KSM_FMA(p, z, 0x1.f1c71c71c71c7p-6);
+    p = KSM_FMA(p, z, 0x1.6db6db6db6db7p-5);
+    p = KSM_FMA(p, z, 0x1.3333333333333p-4);
+    p = KSM_FMA(p, z, 0x1.5555555555555p-3);
     return x + x * (z * p);
 }
 
@@ -187,17 +203,17 @@ KSM_FN double ksm_log(double x)
     double s = f / (2.0 + f);
     double z = s * s;
     double p = 0x1.642c8590b2164p-4;
-    p = p * z + 0x1.8618618618618p-4;
-    p = p * z + 0x1.af286bca1af28p-4;
-    p = p * z + 0x1.e1e1e1e1e1e1ep-4;
-    p = p * z + 0x1.1111111111111p-3;
-    p = p * z + 0x1.3b13b13b13b14p-3;
-    p = p * z + 0x1.745d1745d1746p-3;
-    p = p * z + 0x1.c71c71c71c71cp-3;
-    p = p * z + 0x1.2492492492492p-2;
-    p = p * z + 0x1.999999999999ap-2;
-    p = p * z + 0x1.5555555555555p-1;
-    p = p * z + 0x1.0000000000000p+1;
+    p = KSM_FMA(p, z, 0x1.8618618618618p-4);
+    p = KSM_FMA(p, z, 0x1.af286bca1af28p-4);
+    p = KSM_FMA(p, z, 0x1.e1e1e1e1e1e1ep-4);
+    p = KSM_FMA(p, z, 0x1.1111111111111p-3);
+    p = KSM_FMA(p, z, 0x1.3b13b13b13b14p-3);
+    p = KSM_FMA(p, z, 0x1.745d1745d1746p-3);
+    p = KSM_FMA(p, z, 0x1.c71c71c71c71cp-3);
+    p = KSM_FMA(p, z, 0x1.2492492492492p-2);
+    p = KSM_FMA(p, z, 0x1.999999999999ap-2);
+    p = KSM_FMA(p, z, 0x1.5555555555555p-1);
+    p = KSM_FMA(p, z, 0x1.0000000000000p+1);
     double de = (double)e;
     return de * 0x1.62e42fef00000p-1 + (de * 0x1.473de6af278edp-34 + s * p);
 }
@@ -212,20 +228,20 @@ KSM_FN double ksm_exp(double t)
     double k = __builtin_floor(t * 0x1.71547652b82fep+0 + 0.5);
     double r = (t - k * 0x1.62e42fef00000p-1) - k * 0x1.473de6af278edp-34;
     double p = 0x1.93974a8c07c9dp-37;
-    p = p * r + 0x1.6124613a86d09p-33;
-    p = p * r + 0x1.1eed8eff8d898p-29;
-    p = p * r + 0x1.ae64567f544e4p-26;
-    p = p * r + 0x1.27e4fb7789f5cp-22;
-    p = p * r + 0x1.71de3a556c734p-19;
-    p = p * r + 0x1.a01a01a01a01ap-16;
-    p = p * r + 0x1.a01a01a01a01ap-13;
-    p = p * r + 0x1.6c16c16c16c17p-10;
-    p = p * r + 0x1.1111111111111p-7;
-    p = p * r + 0x1.5555555555555p-5;
-    p = p * r + 0x1.5555555555555p-3;
-    p = p * r + 0x1.0000000000000p-1;
-    p = p * r + 1.0;
-    p = p * r + 1.0;
+    p = KSM_FMA(p, r, 0x1.6124613a86d09p-33);
+    p = KSM_FMA(p, r, 0x1.1eed8eff8d898p-29);
+    p = KSM_FMA(p, r, 0x1.ae64567f544e4p-26);
+    p = KSM_FMA(p, r, 0x1.27e4fb7789f5cp-22);
+    p = KSM_FMA(p, r, 0x1.71de3a556c734p-19);
+    p = KSM_FMA(p, r, 0x1.a01a01a01a01ap-16);
+    p = KSM_FMA(p, r, 0x1.a01a01a01a01ap-13);
+    p = KSM_FMA(p, r, 0x1.6c16c16c16c17p-10);
+    p = KSM_FMA(p, r, 0x1.1111111111111p-7);
+    p = KSM_FMA(p, r, 0x1.5555555555555p-5);
+    p = KSM_FMA(p, r, 0x1.5555555555555p-3);
+    p = KSM_FMA(p, r, 0x1.0000000000000p-1);
+    p = KSM_FMA(p, r, 1.0);
+    p = KSM_FMA(p, r, 1.0);
     int ki = (int)k;
     int k1 = ki >> 1;
     int k2 = ki - k1;

@@ -66,13 +66,11 @@ KSM_FN double ksm_pow2(int e)
     return ksm_from_bits((uint64_t)(e + 1023) << 52);
 }
 
-/* sin r, |r| <= pi/4 (Taylor to r^19, truncation < 1e-19) */
+/* sin r, |r| <= pi/4 (Taylor to r^15, truncation < 6e-17 relative) */
 KSM_FN double ksm_sin_kernel(double r)
 {
     double z = r * r;
-    double p = -0x1.2f49b46814157p-57;
-    p = KSM_FMA(p, z, 0x1.952c77030ad4ap-49);
-    p = KSM_FMA(p, z, -0x1.ae7f3e733b81fp-41);
+    double p = -0x1.ae7f3e733b81fp-41;
     p = KSM_FMA(p, z, 0x1.6124613a86d09p-33);
     p = KSM_FMA(p, z, -0x1.ae64567f544e4p-26);
     p = KSM_FMA(p, z, 0x1.71de3a556c734p-19);
@@ -82,14 +80,11 @@ KSM_FN double ksm_sin_kernel(double r)
     return r + r * (z * p);
 }
 
-/* cos r, |r| <= pi/4 (Taylor to r^20) */
+/* cos r, |r| <= pi/4 (Taylor to r^14, truncation < 1.1e-15) */
 KSM_FN double ksm_cos_kernel(double r)
 {
     double z = r * r;
-    double p = 0x1.e542ba4020225p-62;
-    p = KSM_FMA(p, z, -0x1.6827863b97d97p-53);
-    p = KSM_FMA(p, z, 0x1.ae7f3e733b81fp-45);
-    p = KSM_FMA(p, z, -0x1.93974a8c07c9dp-37);
+    double p = -0x1.93974a8c07c9dp-37;
     p = KSM_FMA(p, z, 0x1.1eed8eff8d898p-29);
     p = KSM_FMA(p, z, -0x1.27e4fb7789f5cp-22);
     p = KSM_FMA(p, z, 0x1.a01a01a01a01ap-16);
@@ -202,9 +197,7 @@ KSM_FN double ksm_log(double x)
     double f = m - 1.0;
     double s = f / (2.0 + f);
     double z = s * s;
-    double p = 0x1.642c8590b2164p-4;
-    p = KSM_FMA(p, z, 0x1.8618618618618p-4);
-    p = KSM_FMA(p, z, 0x1.af286bca1af28p-4);
+    double p = 0x1.af286bca1af28p-4; /* 2/19: the series 2 s (1 + z/3 + z^2/5 + ...) to z^9, truncation < 3e-17 */
     p = KSM_FMA(p, z, 0x1.e1e1e1e1e1e1ep-4);
     p = KSM_FMA(p, z, 0x1.1111111111111p-3);
     p = KSM_FMA(p, z, 0x1.3b13b13b13b14p-3);
@@ -227,9 +220,7 @@ KSM_FN double ksm_exp(double t)
         return 0.0;
     double k = __builtin_floor(t * 0x1.71547652b82fep+0 + 0.5);
     double r = (t - k * 0x1.62e42fef00000p-1) - k * 0x1.473de6af278edp-34;
-    double p = 0x1.93974a8c07c9dp-37;
-    p = KSM_FMA(p, r, 0x1.6124613a86d09p-33);
-    p = KSM_FMA(p, r, 0x1.1eed8eff8d898p-29);
+    double p = 0x1.1eed8eff8d898p-29; /* 1/12!: Taylor to r^12, |r| <= ln2/2, truncation < 2e-16 */
     p = KSM_FMA(p, r, 0x1.ae64567f544e4p-26);
     p = KSM_FMA(p, r, 0x1.27e4fb7789f5cp-22);
     p = KSM_FMA(p, r, 0x1.71de3a556c734p-19);

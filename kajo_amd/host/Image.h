@@ -1,5 +1,9 @@
-// Image.h -- the output image a backend fills (renderer/Image.h:9-21 in the reference):
-// width x height uint32 ARGB8 (A << 24 | R << 16 | G << 8 | B), sRGB-encoded, row 0 = top.
+// Image.h -- stand-in for the frame object a Kajo backend fills, so that hip::Scheduler builds without the
+// Kajo tree. A backend touches exactly three members of the reference's class (renderer/Image.h:9-21), by name:
+//   width, height   frame size in pixels
+//   pixels          width * height words, 0xAARRGGBB, sRGB-encoded, top row first
+// The colour conversion helpers of the reference class are not needed here: the resolve runs on the GPU
+// (kajo_hip_resolve_argb8).
 #ifndef KAJO_HOST_IMAGE_H
 #define KAJO_HOST_IMAGE_H
 
@@ -10,13 +14,14 @@
 class Image
 {
 public:
-    Image(int width, int height);
-    // PNG (8-bit RGBA). The encoder stores the scanlines in uncompressed deflate blocks.
-    bool save(const std::string& fileName) const;
-
-    int width;
-    int height;
+    int width = 0;
+    int height = 0;
     std::unique_ptr<uint32_t[]> pixels;
+
+    Image(int w, int h);
+
+    // Writes an 8-bit RGBA PNG whose scanlines sit in stored (uncompressed) deflate blocks; false on I/O failure.
+    bool save(const std::string& path) const;
 };
 
 #endif

@@ -273,6 +273,29 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
     for (int guard = g.dim[0] + g.dim[1] + g.dim[2] + 3; guard > 0; guard--) {
         const int cell = (cz * g.dim[1] + cy) * g.dim[0] + cx;
         const uint32_t e = lds.gridCellStart[cell + 1];
+#if !KAJO_STRICT
+        if (sc.allTranslated) {
+            // (centre, radius) spheres with the bookkeeping of the brute-force walk: the smaller non-negative root is
+            // the smaller bit pattern, "exists, not behind, closer" one unsigned compare (plus the tie rule)
+            uint32_t kMax = __builtin_bit_cast(uint32_t, tMax);
+            for (uint32_t k = lds.gridCellStart[cell]; k < e; k++) {
+                const int i = (int)lds.gridItems[k];
+                const DFloat4 s = lds.sphereHot[i];
+                F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+                float h = dot(d, o);
+                float c = dot(o, o) - s.w;
+                float sq = __builtin_amdgcn_sqrtf(h * h - aT * c);
+                const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
+                const uint32_t kth = klo < khi ? klo : khi;
+                const int id = np + 1 + i;
+                const bool ok = kth < kMax || (kth == kMax && id > best && kth <= 0x7f800000u);
+                kMax = ok ? kth : kMax;
+                best = ok ? id : best;
+            }
+            tMax = __builtin_bit_cast(float, kMax);
+            bestT0 = tMax;
+        } else
+#endif
         for (uint32_t k = lds.gridCellStart[cell]; k < e; k++) {
             const int i = (int)lds.gridItems[k];
             float ts, th;

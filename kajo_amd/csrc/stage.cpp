@@ -202,7 +202,7 @@ void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
         ext[k] = std::fmax((double)bmax[k] - bmin[k], 1e-3);
         vol *= ext[k];
     }
-    double cellsPerSphere = 4.0;
+    double cellsPerSphere = 1.0; // measured on the 1000-sphere scene: 0.5 .. 2 within 10 %, finer grids lose to the cell stepping
     if (const char* e = std::getenv("KAJO_GRID_CELLS_PER_SPHERE")) // tuning knob
         cellsPerSphere = std::atof(e) > 0 ? std::atof(e) : cellsPerSphere;
     const double side = std::cbrt(vol / (cellsPerSphere * n));

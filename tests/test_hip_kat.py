@@ -61,3 +61,79 @@ def test_shade_strict_equals_oracle(scenes, golden):
         rgb, fin = r.kat_shade(o, d, st)
     assert np.array_equal(fin, wfin)
     assert np.array_equal(rgb.view(np.uint32), want.view(np.uint32))
+
+
+def _adversarial_rays(scene, rng):
+    """Rays chosen to sit on the decisions of the closest-hit walk: origins on and just inside / outside sphere surfaces,
+    tangent directions, rays that leave a sphere through its far side, rays parallel to planes, rays that miss everything."""
+    sp = scene.spheres
+    centres = sp[:, 12:15]  # translation column of the column-major transform
+    radii = sp[:, 38]
+    o, d = [], []
+    unit = lambda v: v / np.linalg.norm(v, axis=-1, keepdims=True)
+    for c, r in zip(centres, radii):
+        n = unit(rng.normal(size=(24, 3)))
+        t = unit(np.cross(n, unit(rng.normal(size=(24, 3)))))
+        for eps in (0.0, 1e-3, -1e-3, 1e-6, -1e-6):
+            p = c + n * (r * (1 + eps))
+            o += [p, p, p, p]
+            d += [n, -n, t, unit(t + 1e-4 * n)]       # outwards, through the centre, tangent, grazing
+        far = c + n * (r * 3)
+        o += [far, far]
+        d += [unit(-n + t * (r / np.sqrt(9 * r * r - r * r))), unit(-n + t * 0.3535)]  # silhouette of the sphere, near it
+    o = np.concatenate(o).astype(np.float32)
+    d = np.concatenate(d).astype(np.float32)
+    axis = np.eye(3, dtype=np.float32)
+    po = rng.uniform(-1, 1, size=(48, 3)).astype(np.float32)
+    pd = np.concatenate([axis, -axis] * 8)            # exactly parallel to the room's planes
+    o = np.concatenate([o, po, rng.uniform(-1, 1, size=(256, 3)).astype(np.float32)])
+    d = np.concatenate([d, pd, unit(rng.normal(size=(256, 3))).astype(np.float32)])
+    return np.ascontiguousarray(o), np.ascontiguousarray(d)
+
+
+@pytest.mark.parametrize("key", ["spheres_a1", "test_a1"])
+def test_trace_adversarial_rays(scenes, key):
+    """The closest-hit bookkeeping on rays that sit on its decisions: STRICT = oracle bit for bit; FAST picks the
+    oracle's object except where the oracle's own answer hangs on the last bits (a root within 1e-4 of zero, of the
+    ray's end, or of another object's root)."""
+    from oraclelib import OracleLib, available
+    if not available("oracle"):
+        pytest.skip("oracle not built")
+    scene = scenes[key]
+    o, d = _adversarial_rays(scene, np.random.default_rng(7))
+    h = OracleLib("oracle").create(scene, 0)
+    want = h.trace(o, d)
+    with HipRenderer(scene, 8, 8, strict=True) as r:
+        strict = r.kat_trace(o, d)
+    assert np.array_equal(strict["idx"], want["idx"])
+    assert np.array_equal(strict["t"].view(np.uint32), want["t"].view(np.uint32))
+    with HipRenderer(scene, 8, 8) as r:
+        fast = r.kat_trace(o, d)
+    differ = fast["idx"] != want["idx"]
+    # distance of each origin from the nearest sphere surface, in radii: for a ray that STARTS on a sphere the reference's
+    # far root is c/q with both c and q cancelled to rounding noise (Raytracer.cpp:36-44) -- not a defined answer
+    centres, radii = scene.spheres[:, 12:15], scene.spheres[:, 38]
+    on_surface = (np.abs(np.linalg.norm(o[:, None, :] - centres[None], axis=-1) - radii[None]) / radii[None]).min(1) < 1e-4
+    # a different object is acceptable only as a near-tie: FAST's own distance is then within 1e-3 of the oracle's,
+    # or one of the two reports a hit at (almost) zero distance from a surface the ray starts on
+    np_ = scene.n_planes
+
+    def grazes(i, idx):  # the ray passes the sphere `idx` hit by one side within 1e-3 radii of its silhouette
+        if idx <= np_:
+            return False
+        c, r = centres[idx - 1 - np_].astype(np.float64), float(radii[idx - 1 - np_])
+        oc = c - o[i].astype(np.float64)
+        dd = d[i].astype(np.float64) / np.linalg.norm(d[i].astype(np.float64))
+        b = np.linalg.norm(oc - dd * np.dot(oc, dd))
+        return abs(b - r) <= 1e-3 * r
+
+    for i in np.nonzero(differ)[0]:
+        tf, tw = float(fast["t"][i]), float(want["t"][i])
+        near_tie = (fast["idx"][i] > 0 and want["idx"][i] > 0 and abs(tf - tw) <= 1e-3 * max(1.0, abs(tw)))
+        at_origin = min(tf if fast["idx"][i] > 0 else np.inf, tw if want["idx"][i] > 0 else np.inf) <= 2e-3
+        grazing_miss = grazes(i, int(fast["idx"][i])) or grazes(i, int(want["idx"][i]))
+        assert near_tie or at_origin or grazing_miss or on_surface[i], (i, fast["idx"][i], want["idx"][i], tf, tw, o[i], d[i])
+    assert differ[~on_surface].mean() <= 0.05, differ[~on_surface].mean()
+    same = ~differ & ~on_surface & (want["idx"] > 0) & np.isfinite(want["t"]) & (want["t"] > 1e-2)
+    assert (np.abs(fast["t"][same] - want["t"][same]) / want["t"][same]).max() <= 2e-3
+    assert np.isfinite(fast["t"][fast["idx"] > 0]).all()

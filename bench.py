@@ -52,6 +52,25 @@ class DevicePtr:
         self.__cuda_array_interface__ = {"shape": (nfloats,), "typestr": "<f4", "data": (ptr, False), "version": 3}
 
 
+def host_cores():
+    """CPU cores this process may really use: the affinity mask, capped by the cgroup CPU quota (the GPU boxes show
+    all hardware threads of the host but grant a quota of a few cores; oversubscribing that only adds throttling)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(math.ceil(int(quota) / int(period)))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, int(math.ceil(q / per))))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def frame_size(n_gpus):
     if n_gpus == 1:
         return 1920, 1080
@@ -80,7 +99,7 @@ def cpu_baseline(scene, W, H):
     snapshot, else this repo's scalar port; on a bounded sample of the same frame."""
     from oraclelib import OracleLib, available
 
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     if available("ref"):
         kind, h = "reference", OracleLib("ref").create(scene)
     else:
@@ -92,7 +111,8 @@ def cpu_baseline(scene, W, H):
     t1c, _ = h.render_native(W, H // 8, 1, 1)  # one thread, an eighth of the rows
     return {
         "value": paths / t / 1e6, "unit": "Msamples/s", "cores": cores, "kind": kind,
-        "sample": "%dx%d, %d pass(es) x 25 paths/px, reference slicing (1 slice per core), %.1f s" % (W, H, passes, t),
+        "sample": "%dx%d, %d pass(es) x 25 paths/px, reference slicing (1 slice per core), %.1f s; cores = affinity mask "
+                  "capped by the cgroup CPU quota (%d hardware threads visible)" % (W, H, passes, t, os.cpu_count() or 0),
         "one_thread_value": W * (H // 8) * 25 / t1c / 1e6,
     }
 
@@ -103,7 +123,7 @@ def parity_leg(scene, W, H, renderer_factory):
     from oraclelib import OracleLib
 
     w, h, passes = 256, 144, PASSES  # the workload's own 512 spp, on a frame the oracle finishes in seconds
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     want = OracleLib("oracle").create(scene, 0).render(w, h, S=SPP, passes=passes, seed=SEED, depth_limit=DEPTH,
                                                         threads=max(1, min(cores, 64)))[..., :3] / passes
     r = renderer_factory(w, h)
@@ -137,7 +157,7 @@ def strict_leg(scene, W, H, local_rank):
     c1 = r.counters()
     r.close()
     w, h = 256, 144
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     want = OracleLib("oracle").create(scene, 1).render(w, h, S=SPP, passes=PASSES, seed=SEED, depth_limit=DEPTH,
                                                         threads=max(1, min(cores, 64)))
     rs = HipRenderer(scene, w, h, spp=SPP, depth_limit=DEPTH, seed=SEED, strict=True, device=local_rank)

@@ -105,7 +105,7 @@ def cpu_baseline(scene, W, H):
     else:
         kind, h = "port", OracleLib("oracle").create(scene, 0)
     t1, _ = h.render_native(W, H, 1, cores)
-    passes = max(1, min(8, int(12.0 / max(t1, 1e-3))))
+    passes = max(1, min(32, int(round(15.0 / max(t1, 1e-3)))))  # about 15 s of CPU work
     t, _ = h.render_native(W, H, passes, cores)
     paths = W * H * 25 * passes
     t1c, _ = h.render_native(W, H // 8, 1, 1)  # one thread, an eighth of the rows

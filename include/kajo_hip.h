@@ -66,7 +66,7 @@ typedef struct KajoParams {
     uint64_t seed;          /* stream seed (reference constant 0715517 = 236367, Random.h:43) */
     uint32_t flags;         /* KAJO_FLAG_* */
     int32_t device;         /* HIP device ordinal */
-    int32_t tileW, tileH;   /* tile size in pixels; multiples of 8; 0 => 64 x 16 */
+    int32_t tileW, tileH;   /* tile size in pixels: multiples of 8 with tileW * tileH a multiple of 256; 0 => 64 x 16 */
     int32_t tileIndex;      /* this handle renders tiles t with t % tileCount == tileIndex */
     int32_t tileCount;      /* number of handles sharing the frame (GPUs); 0 => 1 */
     int32_t passesPerLaunch; /* passes fused into one kernel launch; 0 => library default */

@@ -33,7 +33,8 @@ struct Options
     uint64_t seed = 0715517;      // renderer/cpu/Random.h:43
     int passes = 0;               // stop after this many passes; 0 = until the preview closes
                                   // (16 when there is no preview: the reference never stops by itself)
-    int passesPerUpdate = 1;      // passes rendered between two image/preview refreshes
+    int passesPerUpdate = 0;      // passes rendered between two image/preview refreshes; 0 = automatic: everything that is
+                                  // left (up to 16) without a preview, as many as fit a 30 Hz refresh with one
     int gpus = 1;                 // devices 0 .. gpus-1
     bool strict = false;          // STRICT numerics (bit-identical to the CPU oracle)
     bool counters = false;

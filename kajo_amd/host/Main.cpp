@@ -35,7 +35,7 @@ int main(int argc, char** argv)
                         "    --bounces N     depth limit (8)\n"
                         "    --seed N        stream seed (236367)\n"
                         "    --gpus N        GPUs to tile the frame over (1)\n"
-                        "    --batch N       passes per image refresh (1)\n"
+                        "    --batch N       passes per image refresh (0 = automatic: 16 headless, a 30 Hz refresh with a preview)\n"
                         "    --strict        strict numerics\n"
                         "    --gather MODE   rccl | copy (multi-GPU gather transport)\n"
                         "    --same-device   put every tile owner on GPU 0 (testing; implies --gather copy)\n"

@@ -57,12 +57,6 @@ KDEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 KDEV F3 cross(F3 a, F3 b) { return f3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 KDEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 
-#if defined(KAJO_X_IEEE) && !KAJO_STRICT
-// experiment (tools/flip_experiment.sh): FAST structure with correctly rounded divide / square root
-#define __builtin_amdgcn_rcpf(x) (1.0f / (x))
-#define __builtin_amdgcn_sqrtf(x) __builtin_sqrtf(x)
-#define __builtin_amdgcn_rsqf(x) (1.0f / __builtin_sqrtf(x))
-#endif
 // ---- numerics policy ------------------------------------------------------------------
 #if KAJO_STRICT
 KDEV float kdiv(float a, float b) { return a / b; }
@@ -70,9 +64,19 @@ KDEV float ksqrt(float a) { return __builtin_sqrtf(a); }
 KDEV float krcp(float a) { return 1.0f / a; }
 KDEV float kpow(float x, float y) { return kajo_powf(x, y); }
 #else
-KDEV float kdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
-KDEV float ksqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+// FAST: the hardware's 1-ulp reciprocal, square root and reciprocal square root (profiles/r01_hwmath_accuracy.txt).
+// -DKAJO_X_IEEE swaps in the correctly rounded operations: an experiment (tools/flip_experiment.sh) showing that the
+// pixels where FAST and the oracle part do not come from these approximations.
+#ifdef KAJO_X_IEEE
+KDEV float krcp(float a) { return 1.0f / a; }
+KDEV float ksqrt(float a) { return __builtin_sqrtf(a); }
+KDEV float krsq(float a) { return 1.0f / __builtin_sqrtf(a); }
+#else
 KDEV float krcp(float a) { return __builtin_amdgcn_rcpf(a); }
+KDEV float ksqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+KDEV float krsq(float a) { return __builtin_amdgcn_rsqf(a); }
+#endif
+KDEV float kdiv(float a, float b) { return a * krcp(b); }
 // x >= 0 (clamped cosine / uniform variate / clamped colour): x^y = 2^(y log2 x); v_log(0) = -inf
 // gives 2^-inf = 0 for y > 0, and y == 0 is answered explicitly as libm does (pow(x, 0) = 1)
 KDEV float kpow(float x, float y)
@@ -102,7 +106,7 @@ KDEV F3 normalize(F3 a)
 #if KAJO_STRICT
     return a * (1.0f / __builtin_sqrtf(sqr)); // glm: x * inversesqrt(dot), inversesqrt = 1 / sqrt
 #else
-    return a * __builtin_amdgcn_rsqf(sqr);
+    return a * krsq(sqr);
 #endif
 }
 
@@ -284,7 +288,7 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
                 F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
                 float h = dot(d, o);
                 float c = dot(o, o) - s.w;
-                float sq = __builtin_amdgcn_sqrtf(h * h - aT * c);
+                float sq = ksqrt(h * h - aT * c);
                 const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
                 const uint32_t kth = klo < khi ? klo : khi;
                 const int id = np + 1 + i;
@@ -353,7 +357,7 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
             const DFloat4 r = lds.planeRow[i];
             float denom = r.x * d.x + r.y * d.y + r.z * d.z;
             float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w;
-            const uint32_t kt = __builtin_bit_cast(uint32_t, -oy * __builtin_amdgcn_rcpf(denom));
+            const uint32_t kt = __builtin_bit_cast(uint32_t, -oy * krcp(denom));
             bool ok = !(__builtin_fabsf(denom) < kFltEpsilon) && kt <= kMax;
             kMax = ok ? kt : kMax;
             best = ok ? (int)idV : best;
@@ -402,7 +406,7 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
             float h = dot(d, o);
             float c = dot(o, o) - s.w;
             float discr = h * h - aT * c;
-            float sq = __builtin_amdgcn_sqrtf(discr);
+            float sq = ksqrt(discr);
             const uint32_t klo = __builtin_bit_cast(uint32_t, -h - sq), khi = __builtin_bit_cast(uint32_t, sq - h);
             const uint32_t kth = klo < khi ? klo : khi;
             bool ok = kth <= kMax;
@@ -597,7 +601,7 @@ KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 b
     F3 vv = cross(uu, R);
 #else
     // cross((0,0,1), R) = (-R.y, R.x, 0), written out: the products with the zeros are not folded otherwise
-    const float iu = __builtin_amdgcn_rsqf(R.x * R.x + R.y * R.y);
+    const float iu = krsq(R.x * R.x + R.y * R.y);
     F3 uu = f3(-R.y * iu, R.x * iu, 0.0f);
     F3 vv = f3(uu.y * R.z, -(uu.x * R.z), uu.x * R.y - R.x * uu.y);
 #endif
@@ -649,8 +653,8 @@ KDEV float lightPdf(const DSphereCold& lc, F3 P)
     F3 v = f3(lc.cx - P.x, lc.cy - P.y, lc.cz - P.z);
     float d2 = dot(v, v);
     float r2 = lc.radius * lc.radius;
-    float x2 = r2 * __builtin_amdgcn_rcpf(d2);
-    float p = (1.0f + __builtin_amdgcn_sqrtf(kmax0(1.0f - x2))) * d2 * lc.invTwoPiR2;
+    float x2 = r2 * krcp(d2);
+    float p = (1.0f + ksqrt(kmax0(1.0f - x2))) * d2 * lc.invTwoPiR2;
     return d2 < r2 ? 0.07957747154594767f : p; // inside the light: 1 / (4 pi)
 }
 #endif
@@ -895,7 +899,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     stampLast = __builtin_amdgcn_s_memtime();
 #endif
 #if !KAJO_STRICT
-    const float invS = __builtin_amdgcn_rcpf(args.S);
+    const float invS = krcp(args.S);
 #endif
     uint32_t trips = 0;
     for (;;) {

@@ -40,6 +40,17 @@ void checkNccl(ncclResult_t r, const char* what)
         throw std::runtime_error(std::string(what) + ": " + ncclGetErrorString(r));
 }
 
+// The first float of a 4x4 matrix or 4-vector member of scene::Scene, whatever its C++ type: this repo's stand-in
+// (float[16] / four floats) or the reference's glm::mat4 / glm::vec4 -- both are 16 resp. 4 consecutive floats, column
+// major. `make -C kajo_amd/host refcheck` compiles this file against the reference's own scene/Scene.h, Image.h and
+// Scheduler.h where /root/reference exists.
+template <class T, size_t N>
+const float* floatsOf(const T& v)
+{
+    static_assert(sizeof(T) == N * sizeof(float), "matrix / vector member is not a packed float array");
+    return reinterpret_cast<const float*>(&v);
+}
+
 void copyMaterial(const scene::Material& m, KajoMaterial& k)
 {
     static_assert(sizeof(scene::Material) == sizeof(KajoMaterial), "scene::Material and KajoMaterial share one layout");
@@ -83,18 +94,18 @@ struct Scheduler::Impl
         std::vector<KajoSphere> spheres(s.spheres.size());
         std::vector<KajoPlane> planes(s.planes.size());
         for (size_t i = 0; i < s.spheres.size(); i++) {
-            std::memcpy(spheres[i].transform, s.spheres[i].transform.m, 64);
+            std::memcpy(spheres[i].transform, floatsOf<decltype(s.spheres[i].transform), 16>(s.spheres[i].transform), 64);
             copyMaterial(s.spheres[i].material, spheres[i].material);
             spheres[i].radius = s.spheres[i].radius;
         }
         for (size_t i = 0; i < s.planes.size(); i++) {
-            std::memcpy(planes[i].transform, s.planes[i].transform.m, 64);
+            std::memcpy(planes[i].transform, floatsOf<decltype(s.planes[i].transform), 16>(s.planes[i].transform), 64);
             copyMaterial(s.planes[i].material, planes[i].material);
         }
         KajoScene pod;
-        std::memcpy(pod.backgroundColor, &s.backgroundColor, 16);
-        std::memcpy(pod.camera.transform, s.camera.transform.m, 64);
-        std::memcpy(pod.camera.projection, s.camera.projection.m, 64);
+        std::memcpy(pod.backgroundColor, floatsOf<decltype(s.backgroundColor), 4>(s.backgroundColor), 16);
+        std::memcpy(pod.camera.transform, floatsOf<decltype(s.camera.transform), 16>(s.camera.transform), 64);
+        std::memcpy(pod.camera.projection, floatsOf<decltype(s.camera.projection), 16>(s.camera.projection), 64);
         pod.nSpheres = (int32_t)spheres.size();
         pod.nPlanes = (int32_t)planes.size();
         pod.spheres = spheres.data();

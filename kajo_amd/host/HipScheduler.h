@@ -56,7 +56,10 @@ class Scheduler : public ::Scheduler
 public:
     Scheduler(const scene::Scene&, Image*, Preview*);
     Scheduler(const scene::Scene&, Image*, Preview*, const Options&);
-    ~Scheduler() override;
+    // not marked `override`: the reference's ::Scheduler (renderer/Scheduler.h:12-16) has no virtual destructor -- its
+    // Main.cpp deletes backends through the base pointer at exit, so there this destructor would not run (the process
+    // ends right after; GPU memory goes with it). With this repo's stand-in base it is virtual.
+    ~Scheduler();
 
     void run() override;
 

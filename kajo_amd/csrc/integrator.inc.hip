@@ -396,6 +396,27 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
         // the smaller non-negative root is the smaller bit pattern of the two (see above: a negative root and
         // the NaN of a negative discriminant sort above every acceptable value), so "no root, both behind,
         // beyond the closest so far" is again one unsigned compare.
+#ifdef KAJO_X_REFROOTS
+        // experiment (tools/flip_experiment.sh, with -ffp-contract=off): the reference's own root formulas
+        // (Raytracer.cpp:26-44) in the FAST walk -- do the FAST-vs-oracle path flips come from the root formulas?
+        for (int i = 0; i < ns; i++) {
+            const DFloat4 s = lds.sphereHot[i];
+            F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+            float b = 2 * dot(d, o);
+            float c = dot(o, o) - s.w;
+            float discr = b * b - 4 * aT * c;
+            float sq = __builtin_sqrtf(discr);
+            float q = (b < 0.0f) ? (-b - sq) * .5f : (-b + sq) * .5f;
+            float t0 = q / aT, t1 = c / q;
+            bool sw = t0 > t1;
+            float lo = sw ? t1 : t0, hi = sw ? t0 : t1;
+            float th = (lo < 0.0f) ? hi : lo;
+            bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(th > tMax || th < 0.0f);
+            tMax = ok ? th : tMax;
+            best = ok ? np + 1 + i : best;
+        }
+        return Hit{best, tMax, tMax};
+#endif
         const float tPlane = tMax;
         kMax = __builtin_bit_cast(uint32_t, tMax * aT);
         idV = (uint32_t)np + 1;

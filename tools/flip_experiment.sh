@@ -26,4 +26,5 @@ run baseline
 run nocontract FASTCONTRACT=-ffp-contract=off
 run ieee "KFLAGS=-DKAJO_X_IEEE"
 run ieee_nocontract FASTCONTRACT=-ffp-contract=off "KFLAGS=-DKAJO_X_IEEE"
+run refroots_ieee_nocontract FASTCONTRACT=-ffp-contract=off "KFLAGS=-DKAJO_X_IEEE -DKAJO_X_REFROOTS"
 touch kajo_amd/csrc/kernel_fast.hip; make -s -C kajo_amd/csrc >/dev/null 2>&1

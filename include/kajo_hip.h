@@ -58,6 +58,7 @@ extern "C" {
 #define KAJO_FLAG_COUNTERS 2u /* maintain device-side work counters */
 #define KAJO_FLAG_NO_GRID 4u  /* always walk every sphere (no uniform grid for large scenes) */
 #define KAJO_FLAG_NO_REORDER 8u /* dispatch workgroups in image order (no cost-sorted launch order) */
+#define KAJO_FLAG_NO_SPLIT 16u  /* small frames: do not let several waves share a pixel block and divide the passes */
 
 typedef struct KajoParams {
     int32_t samplesPerPass; /* S: nominal samples per pixel per pass (reference: 32, Renderer.cpp:21);

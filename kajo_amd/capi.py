@@ -21,6 +21,9 @@ LIB_PATH = os.path.join(_HERE, "libkajo_hip.so")
 
 KAJO_FLAG_STRICT = 1
 KAJO_FLAG_COUNTERS = 2
+KAJO_FLAG_NO_GRID = 4
+KAJO_FLAG_NO_REORDER = 8
+KAJO_FLAG_NO_SPLIT = 16
 
 # every symbol include/kajo_hip.h declares
 EXPORTS = [

@@ -25,6 +25,8 @@
 extern "C" {
 int kajo_render_fast_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_strict_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
+int kajo_render_fast_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
+int kajo_render_strict_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_fast_set_lds(int coldInLds, size_t lds);
 int kajo_render_strict_set_lds(int coldInLds, size_t lds);
 int kajo_resolve_fast_launch(const void* frame, int count, float passes, void* dst, void* stream);
@@ -488,15 +490,43 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         if ((rc = getEvent(h, &e0)) || (rc = getEvent(h, &e1)))
             return rc;
         HIP_TRY(hipEventRecord(e0, h->stream));
-        hipError_t le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream)
-                                                 : kajo_render_fast_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream));
+        // Small frames: fewer pixel blocks than a few rounds of the chip's 4096 wave slots. 2 or 4 waves then share a
+        // block and divide the passes of the launch (when they divide evenly); the per-pass terms meet in LDS.
+        unsigned split = 1;
+        const unsigned long long pixelBlocks = (unsigned long long)grid * h->wavesPerBlock;
+        if (h->coldInLds && !(p.flags & KAJO_FLAG_NO_SPLIT)) {
+            // measured (tools/size_sweep.py with KAJO_SPLIT=1..16, 256x144 ... 1920x1080): frames of fewer than three
+            // rounds of the 4096 wave slots run best with the largest power of two -- up to 16 waves per block, as far
+            // as the passes divide -- that keeps the launch within 8 rounds: many short waves pack the tail of the
+            // launch better than few long ones. From 1280x720 on the unsplit kernel is 3-8 % faster.
+            while (pixelBlocks < 3 * 4096 && split < 16 && now % (int)(split * 2) == 0 && pixelBlocks * split * 2 <= 8 * 4096)
+                split *= 2;
+            if (const char* e = std::getenv("KAJO_SPLIT")) { // tuning knob
+                const int v = std::atoi(e);
+                if (v >= 1 && v <= 16 && (v & (v - 1)) == 0 && now % v == 0)
+                    split = (unsigned)v;
+            }
+        }
+        hipError_t le;
+        if (split > 1) {
+            RenderArgs b = a;
+            b.blockOrder = nullptr; // one round or two: the launch order does not matter
+            b.waveTrips = nullptr;
+            const size_t ldsSplit = a.mailboxOffset + (size_t)now * 64 * 16;
+            le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream)
+                                          : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream));
+        } else {
+            le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream)
+                                          : kajo_render_fast_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream));
+        }
         if (le != hipSuccess)
             return failHip(le, "render kernel launch");
         HIP_TRY(hipEventRecord(e1, h->stream));
         h->pending.emplace_back(e0, e1);
-        if (a.waveTrips)
+        if (a.waveTrips && split == 1) {
             h->tripsPending = true;
-        a.waveTrips = nullptr; // later launches of this call keep the first measurement
+            a.waveTrips = nullptr; // later launches of this call keep the first measurement
+        }
         h->launches++;
         h->passesDone += now;
         left -= now;

@@ -798,7 +798,12 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
 
 // KAT (known-answer mode): instead of its pixel's camera paths a lane runs ONE path from a given ray
 // and RNG state and reports its radiance and the RNG state it ends in (kajo_hip_kat_shade).
-template <bool COLD_LDS, bool KAT>
+//
+// SPLIT (small frames): the waves of a workgroup share ONE 8x8-pixel block and divide the launch's passes among
+// them, so that a frame with fewer blocks than the chip has wave slots still fills it. Every pass's term radiance / S
+// goes to an LDS table [pass][pixel]; after a barrier wave 0 adds the terms to the accumulation in pass order -- the
+// float sums are those of one wave doing all the passes.
+template <bool COLD_LDS, bool KAT, bool SPLIT = false>
 KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 {
     const DSceneView& sc = args.scene;
@@ -813,7 +818,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;
     const uint32_t logicalBlock = (!KAT && args.blockOrder) ? args.blockOrder[blockIdx.x] : blockIdx.x;
-    const uint32_t slot = logicalBlock * blockDim.x + threadIdx.x; // index into the tile buffer
+    const int splitWave = SPLIT ? (int)(threadIdx.x >> 6) : 0;
+    const int splitCount = SPLIT ? (int)(blockDim.x >> 6) : 1;
+    const uint32_t slot = SPLIT ? logicalBlock * 64u + (uint32_t)lane : logicalBlock * blockDim.x + threadIdx.x; // index into the tile buffer
+    // SPLIT: per-pass terms of the block, [nPasses][64] float4 behind the scene copy
+    DFloat4* termTable = reinterpret_cast<DFloat4*>(ldsRaw + args.mailboxOffset);
     const int wave = (int)(slot >> 6);
     const int wavesPerTile = (args.tileW >> 3) * (args.tileH >> 3);
     const int ownedTile = wave / wavesPerTile;
@@ -855,18 +864,20 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     // ---- per-lane path state ----------------------------------------------------------------
     int mode = inImage ? MODE_NEW : MODE_DONE;
-    int pass = args.firstPass;                          // pass being rendered (own or taken over)
-    const int lastPass = args.firstPass + args.nPasses; // exclusive
+    const int passesMine = SPLIT ? args.nPasses / splitCount : args.nPasses; // the host launches SPLIT only when this divides
+    const int firstMine = args.firstPass + splitWave * passesMine;
+    int pass = firstMine;                       // pass being rendered (own or taken over)
+    const int lastPass = firstMine + passesMine; // exclusive
     // Pass stealing. A pass of a pixel is a self-contained piece of work (its n*n paths have their own
     // streams, its sum enters the pixel's total as one term), so a lane that has finished its own pixel
     // takes over the LAST not-yet-started pass of a lane that still has several to go, renders it, and
     // leaves radiance / S in a mailbox in LDS; the owner adds the mailbox terms after its own passes, in
     // pass order -- the float sums are formed exactly as without stealing. Only the last KAJO_STEAL_WINDOW
     // passes of a launch can be given away (that is all the imbalance there is, and bounds the mailbox).
-    int ownPass = args.firstPass; // next pass of the lane's own pixel
-    int myEnd = inImage ? lastPass : args.firstPass; // own passes [ownPass, myEnd); shrinks when one is taken over
+    int ownPass = firstMine; // next pass of the lane's own pixel
+    int myEnd = inImage ? lastPass : firstMine; // own passes [ownPass, myEnd); shrinks when one is taken over
     int stolenFrom = -1;          // lane whose pass is being rendered, or -1
-    const int stealBase = lastPass - KAJO_STEAL_WINDOW > args.firstPass ? lastPass - KAJO_STEAL_WINDOW : args.firstPass;
+    const int stealBase = lastPass - KAJO_STEAL_WINDOW > firstMine ? lastPass - KAJO_STEAL_WINDOW : firstMine;
     int sampleX = 0, sampleY = 0;
     F3 radiance = f3(0.0f, 0.0f, 0.0f); // sum over the pixel's samples of this pass
     Rng rng{0, 0};
@@ -952,7 +963,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #else
                 const F3 term = radiance * invS;
 #endif
-                if (stolenFrom >= 0) {
+                if (SPLIT) { // own or taken over: the term goes to the table, under its pass and pixel
+                    termTable[(pass - args.firstPass) * 64 + (stolenFrom >= 0 ? stolenFrom : lane)] = DFloat4{term.x, term.y, term.z, 0.0f};
+                    if (stolenFrom >= 0)
+                        stolenFrom = -1;
+                    else
+                        ownPass++;
+                } else if (stolenFrom >= 0) {
                     mailbox[stolenFrom * KAJO_STEAL_WINDOW + (pass - stealBase)] = DFloat4{term.x, term.y, term.z, 0.0f};
                     stolenFrom = -1;
                 } else {
@@ -1212,7 +1229,16 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
     }
 
-    if (!KAT && inImage) {
+    if (SPLIT) {
+        __syncthreads(); // every wave of the block has left its loop: the table is complete
+        if (splitWave == 0 && inImage) {
+            for (int p = 0; p < args.nPasses; p++) { // Renderer.cpp:70-71, pass by pass
+                const DFloat4 t = termTable[p * 64 + lane];
+                total = total + f3(t.x, t.y, t.z);
+            }
+            reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
+        }
+    } else if (!KAT && inImage) {
         // passes of this pixel that other lanes rendered, in pass order
         for (int p = myEnd; p < lastPass; p++) {
             const DFloat4 t = mailbox[lane * KAJO_STEAL_WINDOW + (p - stealBase)];
@@ -1220,7 +1246,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
         reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
     }
-    if (!KAT && args.waveTrips && lane == 0)
+    if (!KAT && !SPLIT && args.waveTrips && lane == 0)
         args.waveTrips[slot >> 6] = trips;
 
     if (counting && lane == 0) {
@@ -1250,6 +1276,13 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERN
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBody<true, false>(args, ldsRaw);
+}
+
+// small frames: the workgroup's waves share one pixel block and divide the passes (see renderBody)
+extern "C" __global__ void __launch_bounds__(1024, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_SPLIT(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<true, false, true>(args, ldsRaw);
 }
 
 // hot records in LDS, cold ones in global memory (large scenes)

@@ -13,6 +13,13 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _launch)(const RenderArgs* args, int c
     return (int)hipGetLastError();
 }
 
+// small frames: `block` = 64 * (waves sharing one pixel block), grid = pixel blocks
+extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _split_launch)(const RenderArgs* args, unsigned grid, unsigned block, size_t ldsBytes, void* stream)
+{
+    hipLaunchKernelGGL(KAJO_KERNEL_NAME_SPLIT, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
+    return (int)hipGetLastError();
+}
+
 // dynamic LDS above the 64 KiB default needs an explicit opt-in on the function
 extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(int coldInLds, size_t ldsBytes)
 {

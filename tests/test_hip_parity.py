@@ -242,3 +242,20 @@ def test_full_size_properties(scenes):
     want = O.create(sc, 0).render(W, H, S=32, passes=1, seed=SEED, rect=(x0, y0, w, h))[y0:y0 + h, x0:x0 + w, :3]
     s = frame_stats(a[y0:y0 + h, x0:x0 + w, :3], want)
     assert s["median"] <= 1e-5 and s["p99"] <= 5e-3, s
+
+
+@pytest.mark.parametrize("passes", [16, 12, 6, 5])
+def test_pass_splitting_over_waves_is_bit_invariant(O, scenes, passes):
+    """Small frames: several waves share a pixel block and divide the passes of a launch (up to 16 waves for 16 passes;
+    12 -> 4, 6 -> 2, 5 -> none). The per-pass terms are added in pass order, so the buffer is the one a single wave per
+    block produces -- for the FAST kernels bit for bit against KAJO_FLAG_NO_SPLIT, for the STRICT ones against the oracle."""
+    from kajo_amd import capi
+    sc = scenes["spheres_a169"]
+    W, H = 72, 40  # 45 pixel blocks, ragged
+    with HipRenderer(sc, W, H, passes_per_launch=16) as a, HipRenderer(sc, W, H, passes_per_launch=16, flags=capi.KAJO_FLAG_NO_SPLIT) as b:
+        assert bits_equal(a.render(passes).radiance(), b.render(passes).radiance())
+        # and across launches: the accumulation is continued
+        assert bits_equal(a.render(4).radiance(), b.render(4).radiance())
+    want = O.create(sc, 1).render(W, H, S=32, passes=passes, seed=0o715517, depth_limit=8)
+    with HipRenderer(sc, W, H, strict=True, passes_per_launch=16) as r:
+        assert bits_equal(r.render(passes).radiance(), want)

@@ -11,8 +11,13 @@ from kajo_amd.scene import Scene
 
 z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
 sc = Scene.from_npz(z, "spheres_a169/", "spheres")
-for (w, h) in ((128, 72), (256, 144), (512, 288), (640, 360), (960, 540), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160), (7680, 4320)):
-    with HipRenderer(sc, w, h, counters=True) as r:
+from kajo_amd import capi
+NO_SPLIT = capi.KAJO_FLAG_NO_SPLIT if "--no-split" in sys.argv else 0
+SIZES = ((64, 36), (128, 72), (256, 144), (512, 288), (640, 360), (640, 480), (800, 600), (960, 540), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160), (7680, 4320))
+if "--small" in sys.argv:
+    SIZES = ((256, 144), (512, 288), (640, 360), (640, 480), (800, 600), (960, 540), (1280, 720), (1600, 900), (1920, 1080))
+for (w, h) in SIZES:
+    with HipRenderer(sc, w, h, counters=True, flags=NO_SPLIT) as r:
         r.render(16).wait()  # records the trip counts the launch order uses
         c0 = r.counters()
         n = 3

@@ -507,6 +507,8 @@ int kajo_hip_render(kajo_hip_t h, int passes)
                     split = (unsigned)v;
             }
         }
+        if (a.mailboxOffset + (size_t)now * 64 * 16 > 48 * 1024) // the table would need the large-LDS opt-in: not worth it
+            split = 1;
         hipError_t le;
         if (split > 1) {
             RenderArgs b = a;

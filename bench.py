@@ -1,31 +1,35 @@
 #!/usr/bin/env python3
-"""Benchmark of the HIP backend on the reference's headline workload (BASELINE.json).
+"""Benchmark of the HIP backend on the reference's headline workloads (BASELINE.json).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
 
-One STEP = one complete frame of the hot path: spheres.json (parsed-scene fixture), 16:9,
-16 passes x S=32 nominal samples (= "512 spp"; 25 camera paths are traced per pixel per pass,
-renderer/cpu/Renderer.cpp:21,38), depth limit 8, MIS on -- BASELINE.json configs[1] -- rendered
-into HBM, gathered to rank 0 (one RCCL gather of the tile buffers when N > 1), composed and
-resolved to ARGB8 on the device. Inputs (the staged scene) are resident in HBM before the timed
-region; nothing is read back to the host inside it.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself, as a child process
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, rendezvous on 127.0.0.1) -- decided before
+anything touches the GPU; the parent only waits and passes the child's exit code on. Launched under
+torch.distributed.run (the driver's multi-GPU form) the ranks read RANK / LOCAL_RANK / WORLD_SIZE as usual.
 
-N = 1: 1920 x 1080. N > 1: weak scaling -- the pixel count grows with N at fixed 16:9 and fixed
-passes, so every GPU keeps 2.07 Mpx x 400 paths of work (N = 4 is the 3840 x 2160 frame of
-configs[2]); tiles are dealt round-robin over the ranks, there is no collective on the data path
-other than the per-frame gather.
+One STEP = one complete frame of the hot path, rendered into HBM, gathered to rank 0 (ONE RCCL gather of the tile
+buffers when N > 1), composed and resolved to ARGB8 on the device. The staged scene is resident in HBM before the
+timed region; nothing is read back to the host inside it.
 
-value = Msamples/s = camera paths of all ranks / max-over-ranks wall time.
-Rank 0 prints ONE JSON line. The oracle / compiled reference are used ONLY for the cpu_baseline
-and parity legs, never inside the timed region.
+  N = 1   BASELINE configs[1]: data/spheres.json, 1920 x 1080, 512 spp = 16 passes x S=32
+  N > 1   BASELINE configs[2]: data/spheres.json, 3840 x 2160, 2048 spp = 64 passes x S=32, the SAME frame at every
+          N (strong scaling): 64 x 16-pixel tiles dealt round-robin over the ranks, no collective on the data path
+          other than the per-frame gather. (`--workload c3 --gpus 1` renders that frame on one GPU.)
+
+(25 camera paths are traced per pixel per pass, renderer/cpu/Renderer.cpp:21,38; depth limit 8, MIS on.)
+
+value = Msamples/s = camera paths of all ranks / max-over-ranks wall time. Rank 0 prints ONE
+JSON line. The oracle / compiled reference are used ONLY for the cpu_baseline and parity legs, never inside the timed
+region.
 """
 import argparse
 import ctypes as C
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -37,12 +41,17 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-PASSES = 16
 SPP = 32
 DEPTH = 8
 SEED = 0o715517
 PEAK_FP32_TFLOPS = 157.3  # MI355X vector FP32, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+WORKLOADS = {
+    # name: (W, H, passes per frame, passes fused per kernel launch, label)
+    "c2": (1920, 1080, 16, 16, "BASELINE configs[1]"),
+    "c3": (3840, 2160, 64, 32, "BASELINE configs[2]"),
+}
+PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc runs
 
 
 class DevicePtr:
@@ -71,104 +80,118 @@ def host_cores():
     return n
 
 
-def frame_size(n_gpus):
-    if n_gpus == 1:
-        return 1920, 1080
-    s = math.sqrt(n_gpus)
-    w = int(round(1920 * s / 8)) * 8
-    return w, int(round(w * 9 / 16))
-
-
 def flops_per_path(n_planes, n_spheres, traversals_per_path, vertices_per_path):
     """T * (14 nPlanes + 28 nSpheres) + V * 150."""
     return traversals_per_path * (14 * n_planes + 28 * n_spheres) + vertices_per_path * 150
 
 
-def measured_traffic(world, strict, W, H):
-    """HBM bytes per launch of the render kernel from the rocprofv3 PMC passes committed under profiles/
-    (bench.py cannot collect counters itself); only for the exact workload they were taken on."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if world != 1 or strict or (W, H) != (1920, 1080) or not os.path.exists(path):
+def profile_counters(kernel, workload):
+    """PMC figures of the render kernel per launch (HBM bytes; FP32 work actually executed), taken with rocprofv3 --pmc
+    in separate passes over THIS command and committed under profiles/ (bench.py cannot collect counters itself).
+    Returned only for the kernel and workload they were taken on; the source file travels in the line."""
+    if not os.path.exists(PROFILE_COUNTERS):
         return None
-    return json.load(open(path))["traffic_bytes_per_launch"]
+    d = json.load(open(PROFILE_COUNTERS))
+    e = d.get(kernel)
+    if not e or e.get("workload") != workload:
+        return None
+    e = dict(e)
+    e["source"] = os.path.relpath(PROFILE_COUNTERS, ROOT)
+    return e
 
 
 def cpu_baseline(scene, W, H):
     """The reference's own hot loop (cpu::Renderer::render on row slices, one std::async per core,
-    renderer/cpu/Scheduler.cpp:32-42) from the compiled reference when oracle/_ref travelled with the
-    snapshot, else this repo's scalar port; on a bounded sample of the same frame."""
+    renderer/cpu/Scheduler.cpp:32-42) timed on the host cores this box grants, on a bounded sample of the same frame:
+    from the compiled reference (oracle/_ref, kind "reference") when it travelled with the snapshot, and from this
+    repo's scalar port built with the reference's flag set (kind "port") beside it."""
     from oraclelib import OracleLib, available
 
     cores = host_cores()
+    legs = {}
     if available("ref"):
-        kind, h = "reference", OracleLib("ref").create(scene)
-    else:
-        kind, h = "port", OracleLib("oracle").create(scene, 0)
-    t1, _ = h.render_native(W, H, 1, cores)
-    passes = max(1, min(32, int(round(15.0 / max(t1, 1e-3)))))  # about 15 s of CPU work
-    t, _ = h.render_native(W, H, passes, cores)
-    paths = W * H * 25 * passes
-    t1c, _ = h.render_native(W, H // 8, 1, 1)  # one thread, an eighth of the rows
-    return {
-        "value": paths / t / 1e6, "unit": "Msamples/s", "cores": cores, "kind": kind,
-        "sample": "%dx%d, %d pass(es) x 25 paths/px, reference slicing (1 slice per core), %.1f s; cores = affinity mask "
-                  "capped by the cgroup CPU quota (%d hardware threads visible)" % (W, H, passes, t, os.cpu_count() or 0),
-        "one_thread_value": W * (H // 8) * 25 / t1c / 1e6,
-    }
+        legs["reference"] = OracleLib("ref").create(scene)
+    if available("oracle_fast"):
+        legs["port"] = OracleLib("oracle_fast").create(scene, 0)
+    elif available("oracle"):
+        legs["port"] = OracleLib("oracle").create(scene, 0)
+    out = {}
+    budget = 14.0 / max(len(legs), 1)  # seconds of CPU wall time per leg
+    for kind, h in legs.items():
+        t1, _ = h.render_native(W, H, 1, cores)
+        passes = max(1, min(32, int(round(budget / max(t1, 1e-3)))))
+        t, _ = h.render_native(W, H, passes, cores)
+        t1c, _ = h.render_native(W, H // 16, 1, 1)  # one thread, a sixteenth of the rows
+        out[kind] = {"value": W * H * 25 * passes / t / 1e6, "one_thread_value": W * (H // 16) * 25 / t1c / 1e6,
+                     "sample": "%dx%d, %d pass(es) x 25 paths/px, reference slicing (1 slice per core), %.1f s" % (W, H, passes, t)}
+    kind = "reference" if "reference" in out else "port"
+    res = {"value": out[kind]["value"], "unit": "Msamples/s", "cores": cores, "kind": kind,
+           "sample": out[kind]["sample"] + "; cores = affinity mask capped by the cgroup CPU quota (%d hardware threads visible)" % (os.cpu_count() or 0),
+           "one_thread_value": out[kind]["one_thread_value"]}
+    for k, v in out.items():
+        res[k] = v  # both kinds side by side: {"reference": {...}, "port": {...}}
+    return res
 
 
-def parity_leg(scene, W, H, renderer_factory):
-    """Per-pixel RMSE of the radiance estimate against the CPU oracle on a 256 x 144 frame of the
-    same scene/settings (the oracle needs seconds at this size, hours at 1080p)."""
+def parity_leg(scene, make_renderer, strict, passes):
+    """Per-pixel RMSE of the radiance estimate of the timed kernels against the CPU oracle (same numerics mode) on a
+    256 x 144 frame of the same scene/settings (the oracle needs seconds at this size, hours at 1080p)."""
     from oraclelib import OracleLib
 
-    w, h, passes = 256, 144, PASSES  # the workload's own 512 spp, on a frame the oracle finishes in seconds
+    w, h = 256, 144
+    passes = min(passes, 16)
     cores = host_cores()
-    want = OracleLib("oracle").create(scene, 0).render(w, h, S=SPP, passes=passes, seed=SEED, depth_limit=DEPTH,
-                                                        threads=max(1, min(cores, 64)))[..., :3] / passes
-    r = renderer_factory(w, h)
-    got = r.render(passes).radiance()[..., :3] / passes
+    want = OracleLib("oracle").create(scene, 1 if strict else 0).render(w, h, S=SPP, passes=passes, seed=SEED, depth_limit=DEPTH,
+                                                                         threads=max(1, min(cores, 64)))
+    r = make_renderer(w, h)
+    got = r.render(passes).radiance()
     r.close()
+    # bit for bit; a NaN channel (the reference emits them: inf * 0 at grazing glass hits) matches a NaN, whatever its payload
+    same = ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))[..., :3].all(-1)
+    got, want = got[..., :3] / passes, want[..., :3] / passes
     m = np.isfinite(got) & np.isfinite(want)
     d = np.abs(got - want)[m]
     cl = np.where(m, np.clip(got, 0, 1) - np.clip(want, 0, 1), 0.0)
     sq = np.sort((cl ** 2).sum(-1).ravel())[::-1]  # per-pixel squared error, largest first
+    rmse = float(np.sqrt(sq.sum() / cl.size))
     # same streams, different roundings: a 1e-7 difference flips a hit/miss decision in a few paths per
     # million, each moving its pixel by one path's worth of radiance; those few pixels carry the RMSE
-    return {"frame": "%dx%d, %d passes" % (w, h, passes), "median_abs": float(np.median(d)), "p99_abs": float(np.percentile(d, 99)),
-            "rmse_clamped01": float(np.sqrt(sq.sum() / cl.size)),
+    return {"frame": "%dx%d, %d passes, vs oracle (%s math)" % (w, h, passes, "strict" if strict else "libm"),
+            "bit_identical_px": int(same.sum()), "px": int(same.size),
+            "median_abs": float(np.median(d)), "p99_abs": float(np.percentile(d, 99)),
+            "rmse_clamped01": rmse, "meets_north_star_rmse": bool(rmse < 1e-4),
             "rmse_clamped01_without_worst_100_px": float(np.sqrt(sq[100:].sum() / cl.size)),
-            "share_of_sq_error_in_worst_20_px": float(sq[:20].sum() / max(sq.sum(), 1e-300)),
-            "px_off_by_more_than_1e-3": int((np.abs(cl).max(-1) > 1e-3).sum()), "nonfinite_px": int((~m).sum() // 3)}
+            "share_of_sq_error_in_worst_20_px": float(sq[:20].sum() / sq.sum()) if sq.sum() > 0 else None,
+            "px_off_by_more_than_1e-3": int((np.abs(cl).max(-1) > 1e-3).sum()), "nonfinite_px": int((~m).any(-1).sum())}
 
 
-def strict_leg(scene, W, H, local_rank):
-    """The STRICT kernels on the same frame: the mode whose radiance buffer is bit-identical to the CPU oracle (and to
-    the reference's -O2 build up to its own float reassociation): its rate, and the comparison on the parity frame."""
+def other_mode_leg(scene, W, H, passes, ppl, local_rank, strict):
+    """The kernels of the numerics mode that was NOT timed, on the same frame: rate and parity."""
     from kajo_amd.renderer import HipRenderer
-    from oraclelib import OracleLib
 
-    r = HipRenderer(scene, W, H, spp=SPP, depth_limit=DEPTH, seed=SEED, strict=True, device=local_rank)
-    r.render(PASSES).wait()
+    def mk(w, h):
+        return HipRenderer(scene, w, h, spp=SPP, depth_limit=DEPTH, seed=SEED, strict=strict, device=local_rank, passes_per_launch=ppl)
+
+    r = mk(W, H)
+    r.render(passes).wait()
     c0 = r.counters()
     t0 = time.perf_counter()
-    r.render(PASSES).wait()
+    r.render(passes).wait()
     dt = time.perf_counter() - t0
     c1 = r.counters()
     r.close()
-    w, h = 256, 144
-    cores = host_cores()
-    want = OracleLib("oracle").create(scene, 1).render(w, h, S=SPP, passes=PASSES, seed=SEED, depth_limit=DEPTH,
-                                                        threads=max(1, min(cores, 64)))
-    rs = HipRenderer(scene, w, h, spp=SPP, depth_limit=DEPTH, seed=SEED, strict=True, device=local_rank)
-    got = rs.render(PASSES).radiance()
-    rs.close()
-    same = (got.view(np.uint32) == want.view(np.uint32))[..., :3].all(-1)
-    cl = np.nan_to_num(np.clip(got[..., :3], 0, 1) - np.clip(want[..., :3], 0, 1)) / PASSES
-    return {"value": (c1["paths"] - c0["paths"]) / dt / 1e6, "unit": "Msamples/s", "ms_per_step": dt * 1e3,
+    return {"numerics": "strict" if strict else "fast", "value": (c1["paths"] - c0["paths"]) / dt / 1e6, "unit": "Msamples/s",
+            "ms_per_step": dt * 1e3,
             "kernel_ms_per_launch": (c1["kernelMs"] - c0["kernelMs"]) / max(c1["launches"] - c0["launches"], 1),
-            "parity": {"frame": "%dx%d, %d passes, vs oracle (strict math)" % (w, h, PASSES),
-                       "bit_identical_px": int(same.sum()), "px": int(same.size), "rmse_clamped01": float(np.sqrt(np.mean(cl ** 2)))}}
+            "parity": parity_leg(scene, mk, strict, passes)}
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -176,20 +199,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--strict", action="store_true", help="time the STRICT kernels instead of the product path")
+    ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3"],
+                    help="auto: c2 (1080p, 16 passes) on one GPU, c3 (4K, 64 passes, strong scaling) on several")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline / parity / other-mode legs")
+    ap.add_argument("--strict", action="store_true", help="time the STRICT kernels (bit-identical to the oracle)")
+    ap.add_argument("--fast", action="store_true", help="time the FAST kernels")
     ap.add_argument("--passes-per-launch", type=int, default=0)
+    ap.add_argument("--no-check", action="store_true", help="N > 1: skip the bit-for-bit check against a one-GPU frame")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 control flow on fewer GPUs than ranks (gather staged through "
                          "host memory, every rank on GPU LOCAL_RANK %% device_count); the graded runs use nccl = RCCL")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        # Start the ranks as a CHILD process; this process has not touched the GPU (importing torch does not).
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+    world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the backend has no CPU path")
@@ -205,19 +237,28 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
+    from kajo_amd import capi
     from kajo_amd.renderer import HipRenderer
     from kajo_amd.scene import Scene
     from kajo_amd.tiles import gather_to_root
 
+    wl = args.workload if args.workload != "auto" else ("c2" if world == 1 else "c3")
+    W, H, PASSES, ppl_default, wl_label = WORKLOADS[wl]
+    ppl = args.passes_per_launch or ppl_default
+    strict = bool(args.strict) and not args.fast
     z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
     scene = Scene.from_npz(z, "spheres_a169/", "spheres.json 16:9")
-    W, H = frame_size(world)
 
     def factory(w, h, **kw):
-        return HipRenderer(scene, w, h, spp=SPP, depth_limit=DEPTH, seed=SEED, strict=args.strict, device=local_rank,
-                           passes_per_launch=args.passes_per_launch, **kw)
+        kw.setdefault("strict", strict)
+        return HipRenderer(scene, w, h, spp=SPP, depth_limit=DEPTH, seed=SEED, device=local_rank, passes_per_launch=ppl, **kw)
 
+    # ONE stream carries the whole step -- render, gather (RCCL orders itself against the current stream on both
+    # sides), compose, resolve -- so the next frame's kernel cannot touch a tile buffer that is still being sent.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
     r = factory(W, H, tile_index=rank, tile_count=world)
+    r.set_stream(stream.cuda_stream)
     ptr, nbytes = r.tile_buffer()
     mine = torch.as_tensor(DevicePtr(ptr, nbytes // 4), device="cuda")
     gathered = None
@@ -225,11 +266,14 @@ def main():
     if world > 1 and rank == 0:
         gathered = torch.empty(world * (nbytes // 4), dtype=torch.float32, device="cuda")
     L = r._L
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    gather_ms, tail_ms = [], []
 
-    def step():
+    def step(timed=False):
         r.render(PASSES)
         r.wait()
         if world > 1:
+            ev[0].record()
             if args.backend == "nccl":
                 gather_to_root(dist, mine, gathered, rank, world)
             else:  # rehearsal: gloo moves host tensors
@@ -237,13 +281,16 @@ def main():
                 gather_to_root(dist, mine.cpu(), host, rank, world)
                 if rank == 0:
                     gathered.copy_(host)
+            ev[1].record()
             if rank == 0:
-                torch.cuda.current_stream().synchronize()
                 r.compose(gathered.data_ptr())
         if rank == 0:
-            from kajo_amd import capi
             capi.check(L.kajo_hip_resolve_argb8_device(r._h, C.c_void_p(argb.data_ptr())))
-            r.wait()
+        ev[2].record()
+        stream.synchronize()
+        if timed and world > 1:
+            gather_ms.append(ev[0].elapsed_time(ev[1]))
+            tail_ms.append(ev[1].elapsed_time(ev[2]))
 
     def fence():
         if world > 1:
@@ -256,24 +303,59 @@ def main():
     c0 = r.counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        step(True)
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     c1 = r.counters()
+    dt = dt_local
+    per_rank = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+        dev = "cuda" if args.backend == "nccl" else "cpu"
+        t = torch.tensor([dt_local], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        mine_stats = torch.tensor([(c1["kernelMs"] - c0["kernelMs"]) / max(args.steps, 1), float(np.mean(gather_ms or [0.0])),
+                                   (c1["paths"] - c0["paths"]) / max(args.steps, 1)], dtype=torch.float64, device=dev)
+        allst = [torch.zeros_like(mine_stats) for _ in range(world)]
+        dist.all_gather(allst, mine_stats)
+        per_rank = [[float(v) for v in s.tolist()] for s in allst]
 
     n = int(math.sqrt(SPP))
     paths_per_step = W * H * n * n * PASSES
     value = paths_per_step * args.steps / dt / 1e6
 
+    # ---- N > 1: the composed frame against ONE GPU rendering the same frame alone, bit for bit (2 steps) ---------
+    check = None
+    if world > 1 and not args.no_check:
+        r.reset()
+        for _ in range(2):
+            step()
+        fence()
+        if rank == 0:
+            got = r.radiance()
+            solo = factory(W, H)
+            solo.render(PASSES).wait()  # warm: the first launch also records the launch order
+            s0 = solo.counters()
+            ts = time.perf_counter()
+            solo.render(PASSES).wait()
+            solo_dt = time.perf_counter() - ts
+            s1 = solo.counters()
+            want = solo.radiance()
+            solo.close()
+            same = np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            solo_value = (s1["paths"] - s0["paths"]) / solo_dt / 1e6
+            check = {"frame_bit_identical_to_one_gpu": bool(same), "steps_compared": 2,
+                     "one_gpu_same_frame_value": solo_value, "one_gpu_same_frame_ms": solo_dt * 1e3,
+                     "speedup_vs_one_gpu_same_frame": value / solo_value,
+                     "efficiency_vs_one_gpu_same_frame": value / solo_value / world}
+        fence()
+
     out = None
     if rank == 0:
+        kernel = "kajo_render_strict" if strict else "kajo_render_fast"
         # work per path from the device counters of a separate, untimed frame (deterministic)
         rc = factory(W, H, tile_index=0, tile_count=world, counters=True)
-        cc = rc.render(PASSES).counters()
+        cc = rc.render(min(PASSES, 16)).counters()
         rc.close()
         trav = cc["traversals"] / cc["paths"]
         vert = cc["vertices"] / cc["paths"]
@@ -284,39 +366,58 @@ def main():
         achieved = fpp * paths_per_launch / (kernel_ms * 1e-3) / 1e12
         owned_px = (c1["paths"] - c0["paths"]) / (n * n * PASSES * args.steps)
         hbm_gbs = 32.0 * owned_px / (kernel_ms * 1e-3) / 1e9  # float4 read + write per pixel per launch
-        prop = torch.cuda.get_device_properties(local_rank)
-        cus, clock_ghz = prop.multi_processor_count, getattr(prop, "clock_rate", 2400000) / 1e6  # one v_fma_f32 per lane per cycle
+        workload = ("data/spheres.json (parsed-scene fixture), %dx%d, %d spp = %d passes x S=32 (25 camera paths/px/pass), "
+                    "depth 8, MIS on; %s" % (W, H, PASSES * SPP, PASSES, wl_label))
+        pc = profile_counters(kernel, wl) if world == 1 else None
+        roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / PEAK_FP32_TFLOPS,
+                "traffic": pc["hbm_bytes_per_launch"] if pc else None,
+                "traffic_source": (pc["source"] + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, round 2, this command)") if pc else None,
+                "kernel": kernel, "kernel_ms_per_launch": kernel_ms, "launches_per_step": launches / args.steps,
+                "passes_per_launch": ppl,
+                "flops_per_path": fpp, "traversals_per_path": trav, "vertices_per_path": vert,
+                "lane_efficiency": cc["traversals"] / max(cc["laneSlots"], 1),
+                "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
+                        "algorithmic_bytes_per_launch": 32.0 * owned_px}}
+        if pc:
+            # FP32 work the launch really executed: the PMC FLOP count x the share of lanes that were active
+            roof["executed_flops"] = {"per_launch": pc["executed_fp32_flops_per_launch"],
+                                      "tflops": pc["executed_fp32_flops_per_launch"] / (kernel_ms * 1e-3) / 1e12,
+                                      "valu_lane_utilisation": pc["valu_lane_utilisation"], "source": pc["source"]}
         out = {
             "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "data/spheres.json (parsed-scene fixture), %dx%d, 512 spp = 16 passes x S=32 "
-                                   "(25 camera paths/px/pass), depth 8, MIS on; BASELINE configs[1]%s" %
-                                   (W, H, "" if world == 1 else " scaled to %d GPUs at 2.07 Mpx per GPU" % world),
-                       "numerics": "strict" if args.strict else "fast", "tiles": "64x16 round-robin over ranks",
-                       "paths_per_step": paths_per_step},
-            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_TFLOPS,
-                         "frac_of_unpacked_fma_peak": achieved / (cus * 64 * 2 * clock_ghz * 1e-3),
-                         "unpacked_fma_peak": cus * 64 * 2 * clock_ghz * 1e-3, "traffic": measured_traffic(world, args.strict, W, H),
-                         "kernel": "kajo_render_strict" if args.strict else "kajo_render_fast",
-                         "kernel_ms_per_launch": kernel_ms, "launches_per_step": launches / args.steps,
-                         "flops_per_path": fpp, "traversals_per_path": trav, "vertices_per_path": vert,
-                         "lane_efficiency": cc["traversals"] / max(cc["laneSlots"], 1),
-                         "hbm": {"achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_gbs / PEAK_HBM_GBS,
-                                 "algorithmic_bytes_per_launch": 32.0 * owned_px}},
+            "config": {"workload": workload, "numerics": "strict" if strict else "fast",
+                       "tiles": "64x16 round-robin over ranks", "paths_per_step": paths_per_step,
+                       "world_size_seen_by_backend": (dist.get_world_size() if world > 1 else 1),
+                       "backend": (args.backend if world > 1 else None)},
+            "roofline": roof,
             "in_kernel_value": paths_per_launch / (kernel_ms * 1e-3) / 1e6 * world,
             "mtraversals_per_s": value * trav,
             "nominal_rays_x_spp_x_bounces_per_s_M": W * H * n * n * PASSES * DEPTH * args.steps / dt / 1e6,
         }
+        if per_rank:
+            km = [p[0] for p in per_rank]
+            out["multi_gpu"] = {"kernel_ms_per_step_by_rank": km, "kernel_ms_imbalance": max(km) / max(min(km), 1e-9),
+                                "gather_ms_by_rank": [p[1] for p in per_rank],
+                                "compose_resolve_ms_rank0": float(np.mean(tail_ms or [0.0])),
+                                "paths_per_step_by_rank": [p[2] for p in per_rank],
+                                "gather_bytes_per_peer": nbytes}
+            if check:
+                out["multi_gpu"].update(check)
     r.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene, W, H)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        out["parity"] = parity_leg(scene, W, H, factory)
-        if not args.strict:
-            out["strict_mode"] = strict_leg(scene, W, H, local_rank)
-            out["strict_mode"]["speedup_vs_cpu_baseline"] = out["strict_mode"]["value"] / out["cpu_baseline"]["value"]
+        out["parity"] = parity_leg(scene, factory, strict, PASSES)
+        other = other_mode_leg(scene, W, H, PASSES, ppl, local_rank, not strict)
+        other["speedup_vs_cpu_baseline"] = other["value"] / out["cpu_baseline"]["value"]
+        out["strict_mode" if not strict else "fast_mode"] = other
+        meets = [m for m, p in (("strict" if strict else "fast", out["parity"]), (other["numerics"], other["parity"]))
+                 if p["meets_north_star_rmse"]]
+        out["modes_meeting_north_star_rmse_1e-4"] = meets
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

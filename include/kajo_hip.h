@@ -93,11 +93,15 @@ void kajo_hip_default_params(KajoParams* p);
 int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoParams* params, kajo_hip_t* out);
 int kajo_hip_destroy(kajo_hip_t h); /* NULL is accepted */
 
-/* Enqueue `passes` more passes (pass numbers continue from the handle's count, first = 1). */
+/* Enqueue `passes` more passes (pass numbers continue from the handle's count, first = 1; at most 2^31 - 1 in all). */
 int kajo_hip_render(kajo_hip_t h, int passes);
 int kajo_hip_wait(kajo_hip_t h);
 /* Zero the accumulation and restart the pass numbering at 1. */
 int kajo_hip_reset(kajo_hip_t h);
+/* Continue the pass numbering from `passesDone` (the next pass rendered is passesDone + 1) without touching the
+   accumulation: the reference's loop `for (pass = 1;; pass++)` (Renderer.cpp:44) has no end, and a progressive
+   session may be carried on from any pass number. Pass numbers run to 2^31 - 1 (include/kajo_stream.h). */
+int kajo_hip_set_pass_count(kajo_hip_t h, int passesDone);
 
 /* Whole-frame outputs; valid when tileCount == 1, or on a handle that has been composed.
    dst are HOST pointers: width*height uint32 ARGB8 (row 0 = top) / width*height*4 floats

@@ -43,7 +43,9 @@ KAJO_HD uint32_t kajo_rotl32(uint32_t x, int r)
     } while (0)
 
 /*
- * pass:   1-based pass number, as the reference counts them (Renderer.cpp:44), < 2^16
+ * pass:   1-based pass number, as the reference counts them (Renderer.cpp:44: `for (pass = 1;; pass++)`, unbounded);
+ *         its low 16 bits share key word b with the sample index, the bits above them enter key word c
+ *         (zero for the first 65535 passes, so those streams are the ones of the 16-bit protocol)
  * sample: sampleY * n + sampleX, n = (int)sqrt(S) (Renderer.cpp:38,51-53), < 2^16
  * pixel:  y * W + x in whole-image coordinates, row 0 = top, < 2^32
  * state:  [0] = low 64 bits, [1] = high 64 bits of the __m128i
@@ -53,7 +55,7 @@ KAJO_HD void kajo_stream_state(uint64_t seed, uint32_t pass, uint32_t sample, ui
 {
     uint32_t a = pixel ^ 0x61707865u;
     uint32_t b = (sample | (pass << 16)) ^ 0x3320646eu;
-    uint32_t c = (uint32_t)seed ^ 0x79622d32u;
+    uint32_t c = (uint32_t)seed ^ (pass >> 16) ^ 0x79622d32u;
     uint32_t d = (uint32_t)(seed >> 32) ^ 0x6b206574u;
     KAJO_QUARTER_ROUND(a, b, c, d);
     KAJO_QUARTER_ROUND(a, b, c, d);

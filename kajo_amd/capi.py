@@ -17,7 +17,8 @@ import torch  # noqa: F401  (plumbing: device memory, streams, torch.distributed
 from .scene import KajoScene
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libkajo_hip.so")
+# KAJO_HIP_LIB: a diagnostic twin of the library (e.g. the -DKAJO_PROFILE build of `make prof`); never a CPU path
+LIB_PATH = os.environ.get("KAJO_HIP_LIB") or os.path.join(_HERE, "libkajo_hip.so")
 
 KAJO_FLAG_STRICT = 1
 KAJO_FLAG_COUNTERS = 2
@@ -28,7 +29,7 @@ KAJO_FLAG_NO_SPLIT = 16
 # every symbol include/kajo_hip.h declares
 EXPORTS = [
     "kajo_hip_default_params", "kajo_hip_create", "kajo_hip_destroy", "kajo_hip_render", "kajo_hip_wait",
-    "kajo_hip_reset", "kajo_hip_resolve_argb8", "kajo_hip_read_radiance", "kajo_hip_resolve_argb8_device",
+    "kajo_hip_reset", "kajo_hip_set_pass_count", "kajo_hip_resolve_argb8", "kajo_hip_read_radiance", "kajo_hip_resolve_argb8_device",
     "kajo_hip_tile_buffer", "kajo_hip_compose", "kajo_hip_set_stream", "kajo_hip_counters",
     "kajo_hip_stage_scene", "kajo_hip_last_error", "kajo_hip_version", "kajo_hip_kat_trace", "kajo_hip_kat_shade",
     "kajo_hip_kat_strictmath",
@@ -80,6 +81,7 @@ def lib():
         L.kajo_hip_render.argtypes = [C.c_void_p, C.c_int]
         L.kajo_hip_wait.argtypes = [C.c_void_p]
         L.kajo_hip_reset.argtypes = [C.c_void_p]
+        L.kajo_hip_set_pass_count.argtypes = [C.c_void_p, C.c_int]
         L.kajo_hip_resolve_argb8.argtypes = [C.c_void_p, C.c_void_p]
         L.kajo_hip_read_radiance.argtypes = [C.c_void_p, C.c_void_p]
         L.kajo_hip_resolve_argb8_device.argtypes = [C.c_void_p, C.c_void_p]

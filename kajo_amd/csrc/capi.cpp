@@ -361,9 +361,10 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     h->hotBytes = hotBytes + gridBytes; // what the big-scene staging (and the known-answer kernels) put in LDS
     h->coldInLds = hotBytes + coldBytes <= 40 * 1024 && !st.gridEnabled;
     h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0) + gridBytes;
-    if (h->ldsBytes > 160 * 1024) {
+    // scene copy + the pass-stealing mailboxes of a 4-wave workgroup (64 lanes x 4 passes x float4 per wave) must fit a CU
+    if (((h->ldsBytes + 15) & ~(size_t)15) + 4 * 4096 > 160 * 1024) {
         destroy(h);
-        return fail(KAJO_E_INVALID, "scene exceeds the 160 KiB LDS staging limit (hot records)");
+        return fail(KAJO_E_INVALID, "scene exceeds the LDS staging limit: hot records + 16 KiB of mailboxes must fit 160 KiB");
     }
     // ---- tiles -----------------------------------------------------------------------------
     TileMap& m = h->map;
@@ -440,8 +441,8 @@ int kajo_hip_render(kajo_hip_t h, int passes)
 {
     if (!h)
         return fail(KAJO_E_INVALID, "null handle");
-    if (passes < 0 || h->passesDone + (long long)passes > 65535)
-        return fail(KAJO_E_INVALID, "pass count out of range (stream key holds 16 bits)");
+    if (passes < 0 || h->passesDone + (long long)passes > 0x7fffffffll)
+        return fail(KAJO_E_INVALID, "pass count out of range (2^31 - 1 passes per handle)");
     int rc = bind(h);
     if (rc)
         return rc;
@@ -521,8 +522,11 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream)
                                           : kajo_render_fast_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream));
         }
-        if (le != hipSuccess)
+        if (le != hipSuccess) {
+            h->eventPool.push_back(e0);
+            h->eventPool.push_back(e1);
             return failHip(le, "render kernel launch");
+        }
         HIP_TRY(hipEventRecord(e1, h->stream));
         h->pending.emplace_back(e0, e1);
         if (a.waveTrips && split == 1) {
@@ -592,6 +596,18 @@ int kajo_hip_reset(kajo_hip_t h)
     h->frameValid = false;
     h->kernelMs = 0.0;
     h->launches = 0;
+    return KAJO_OK;
+}
+
+int kajo_hip_set_pass_count(kajo_hip_t h, int passesDone)
+{
+    if (!h || passesDone < 0)
+        return fail(KAJO_E_INVALID, "invalid argument");
+    int rc = kajo_hip_wait(h);
+    if (rc)
+        return rc;
+    h->passesDone = passesDone;
+    h->frameValid = false;
     return KAJO_OK;
 }
 

@@ -357,7 +357,10 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
             const DFloat4 r = lds.planeRow[i];
             float denom = r.x * d.x + r.y * d.y + r.z * d.z;
             float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w;
-            const uint32_t kt = __builtin_bit_cast(uint32_t, -oy * krcp(denom));
+            // (+ 0.0f: an origin exactly ON the plane gives t = -0.0 for one sign of denom, which the reference accepts --
+            // `t < 0` is false, Raytracer.cpp:85-86,115 -- while its bit pattern would sort above +inf; x + (+0) turns -0
+            // into +0 and leaves every other value as it is, and rides on the multiply as one FMA)
+            const uint32_t kt = __builtin_bit_cast(uint32_t, __builtin_fmaf(-oy, krcp(denom), 0.0f));
             bool ok = !(__builtin_fabsf(denom) < kFltEpsilon) && kt <= kMax;
             kMax = ok ? kt : kMax;
             best = ok ? (int)idV : best;
@@ -836,7 +839,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     const int n = args.n;
     const uint32_t pixelIndex = (uint32_t)(py * args.W + px);
-    // include/kajo_stream.h: key words (pixel, sample | pass << 16, seed lo, seed hi) ^ constants
+    // include/kajo_stream.h: key words (pixel, sample | pass << 16, seed lo ^ pass >> 16, seed hi) ^ constants
     const uint32_t keyA = pixelIndex ^ 0x61707865u;
     const uint32_t keyC = (uint32_t)args.seed ^ 0x79622d32u;
     const uint32_t keyD = (uint32_t)(args.seed >> 32) ^ 0x6b206574u;
@@ -1011,7 +1014,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 idleMask &= idleMask - 1; // next idle lane
             }
             if (mode == MODE_NEW && (stolenFrom >= 0 || ownPass < myEnd)) {
-                uint32_t a = curKeyA, c = keyC, dd = keyD;
+                uint32_t a = curKeyA, c = keyC ^ ((uint32_t)pass >> 16), dd = keyD;
                 uint32_t b = ((uint32_t)(sampleY * n + sampleX) | ((uint32_t)pass << 16)) ^ 0x3320646eu;
                 KAJO_QUARTER_ROUND(a, b, c, dd);
                 KAJO_QUARTER_ROUND(a, b, c, dd);

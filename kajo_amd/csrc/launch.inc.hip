@@ -20,11 +20,20 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _split_launch)(const RenderArgs* args,
     return (int)hipGetLastError();
 }
 
-// dynamic LDS above the 64 KiB default needs an explicit opt-in on the function
+// Dynamic LDS above the 64 KiB default needs an explicit opt-in on the function. The attribute is state of the
+// FUNCTION, shared by every handle of the process: it is only ever raised (a later, smaller scene must not lower the
+// limit under an earlier handle's launches).
 extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(int coldInLds, size_t ldsBytes)
 {
+    static size_t highWater[2] = {0, 0};
+    const int k = coldInLds ? 1 : 0;
+    if (ldsBytes <= highWater[k])
+        return (int)hipSuccess;
     const void* fn = coldInLds ? reinterpret_cast<const void*>(KAJO_KERNEL_NAME) : reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIG);
-    return (int)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    if (e == hipSuccess)
+        highWater[k] = ldsBytes;
+    return (int)e;
 }
 
 extern "C" int KAJO_CAT(KAJO_RESOLVE_NAME, _launch)(const void* frame, int count, float passes, void* dst, void* stream)

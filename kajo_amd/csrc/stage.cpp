@@ -185,6 +185,15 @@ void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
     const int n = s.nSpheres;
     if (n < gridMinSpheres || gridMinSpheres <= 0)
         return;
+    // The walk compares the reported distances t * determinant (Raytracer.cpp:71,97) with WORLD-space cell
+    // boundaries, which is only sound when the two agree: every sphere determinant exactly 1 (t itself is the world-space
+    // ray parameter under any affine transform) and every plane rigid to within float rounding (far inside the
+    // registration margin below). A scaled sphere (det != 1) anywhere keeps the every-sphere walk.
+    if (!out.planesRigid)
+        return;
+    for (int i = 0; i < n; i++)
+        if (out.invDet[17 * ((size_t)s.nPlanes + i) + 16] != 1.f)
+            return;
     std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
     float bmin[3] = {3e38f, 3e38f, 3e38f}, bmax[3] = {-3e38f, -3e38f, -3e38f};
     for (int i = 0; i < n; i++) {

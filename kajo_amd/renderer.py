@@ -73,6 +73,10 @@ class HipRenderer:
         capi.check(self._L.kajo_hip_reset(self._h))
         self.passes = 0
 
+    def set_pass_count(self, passes_done: int):
+        capi.check(self._L.kajo_hip_set_pass_count(self._h, int(passes_done)))
+        self.passes = int(passes_done)
+
     def set_stream(self, stream_ptr: int):
         capi.check(self._L.kajo_hip_set_stream(self._h, C.c_void_p(stream_ptr)))
 

@@ -342,6 +342,10 @@ struct Oracle
     V3 background;
     M4 view, proj;
     V3 p1, p2, p3, origin;
+    // Timing only (koracle_render_native): also execute the closest-hit walks that
+    // Shader::calculateLightProbabilities repeats for every light (Shader.cpp:88-111), so that the port does the
+    // reference's amount of work when it stands in for it as the CPU baseline. Results do not depend on it.
+    bool timingRetrace = false;
 
     explicit Oracle(const KajoScene& s)
     {
@@ -752,6 +756,8 @@ struct Oracle
                 const OSphere& light = spheres[i];
                 if (!light.isLight || 1 + np + i == sp.id)
                     continue;
+                if (timingRetrace && trace(o, d, nullptr).id != next.id) // Raytracer.cpp:140-144, same ray: never taken
+                    continue;
                 if (next.id != 1 + np + i)
                     continue;
                 pL += 1 / solidAngle<M>(light, sp.position);
@@ -1074,6 +1080,7 @@ void koracle_resolve(int math, int n, const float* accum, int pass, uint32_t* pi
 double koracle_render_native(void* hh, int W, int Hh, int passes, int nThreads, int depthLimit, float* accum)
 {
     Handle* H = static_cast<Handle*>(hh);
+    H->o->timingRetrace = true;
     const Oracle& o = *H->o;
     const int S = 32;
     Oracle::FrameConsts c = Oracle::frameConsts(W, Hh, S);
@@ -1108,6 +1115,7 @@ double koracle_render_native(void* hh, int W, int Hh, int passes, int nThreads, 
     for (auto& th : pool)
         th.join();
     auto t1 = std::chrono::steady_clock::now();
+    H->o->timingRetrace = false;
     return std::chrono::duration<double>(t1 - t0).count();
 }
 

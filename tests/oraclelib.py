@@ -1,6 +1,7 @@
 """ctypes bindings of the parity checkers. TEST INFRASTRUCTURE ONLY.
 
   OracleLib("oracle")      -> oracle/libkajo_oracle.so  (this repo's CPU restatement)
+  OracleLib("oracle_fast") -> oracle/libkajo_oracle_fast.so (the same, reference flag set; CPU-baseline timing only)
   OracleLib("ref")         -> oracle/_ref/libkajo_ref.so        (the compiled reference, fast flags)
   OracleLib("ref_strict")  -> oracle/_ref/libkajo_ref_strict.so (the compiled reference, -O2)
 
@@ -19,6 +20,7 @@ from kajo_amd.scene import KajoPlane, KajoScene, KajoSphere, Scene
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATHS = {
     "oracle": os.path.join(ROOT, "oracle", "libkajo_oracle.so"),
+    "oracle_fast": os.path.join(ROOT, "oracle", "libkajo_oracle_fast.so"),  # reference flag set: timing only
     "ref": os.path.join(ROOT, "oracle", "_ref", "libkajo_ref.so"),
     "ref_strict": os.path.join(ROOT, "oracle", "_ref", "libkajo_ref_strict.so"),
 }

@@ -5,7 +5,7 @@ radiance to rounding), the FAST kernels to the reference-vs-reference floor."""
 import numpy as np
 import pytest
 
-from kajo_amd.renderer import HipRenderer
+from kajo_amd.renderer import HipRenderer, stage_scene
 
 pytestmark = pytest.mark.gpu
 
@@ -137,3 +137,54 @@ def test_trace_adversarial_rays(scenes, key):
     same = ~differ & ~on_surface & (want["idx"] > 0) & np.isfinite(want["t"]) & (want["t"] > 1e-2)
     assert (np.abs(fast["t"][same] - want["t"][same]) / want["t"][same]).max() <= 2e-3
     assert np.isfinite(fast["t"][fast["idx"] > 0]).all()
+
+
+def test_trace_origin_exactly_on_a_surface(scenes):
+    """t = -0.0 / +0.0: a ray whose origin lies EXACTLY on a plane (oy == 0) or on a sphere (c == 0) is accepted by the
+    reference at distance zero (`t < 0` is false for either zero, Raytracer.cpp:85-86,115; q = 0 gives t0 = 0,
+    Raytracer.cpp:36-52). STRICT must agree on every such ray; FAST on those where "exactly on the surface" does not
+    depend on how the dot products are rounded (unrotated planes, spheres whose centre + radius is exact): its
+    bit-pattern compare once took -0.0 for "behind the origin"."""
+    from oraclelib import OracleLib, available
+    if not available("oracle"):
+        pytest.skip("oracle not built")
+    scene = scenes["spheres_a169"]
+    inv, _ = stage_scene(scene)
+    o, d, robust = [], [], []
+    rng = np.random.default_rng(3)
+    for i in range(scene.n_planes):
+        M = scene.planes[i, :16].reshape(4, 4).astype(np.float64)  # column-major: rows of this array are columns
+        # points of the plane (local y = 0) whose float32 coordinates give oy == 0 exactly: searched, not assumed
+        row = inv[i, [1, 5, 9, 13]]  # row y of the inverse
+        for _ in range(400):
+            loc = np.array([rng.integers(-8, 9) * .5, 0.0, rng.integers(-8, 9) * .5, 1.0])
+            P = (loc @ M)[:3].astype(np.float32)
+            oy = np.float32(np.float32(np.float32(row[0] * P[0]) + np.float32(row[1] * P[1])) + np.float32(row[2] * P[2])) + row[3]
+            if oy == 0:
+                for sgn in (1.0, -1.0):
+                    dd = rng.normal(size=3)
+                    dd[1] = abs(dd[1]) * sgn + sgn * .2
+                    o.append(P)
+                    d.append((dd / np.linalg.norm(dd)).astype(np.float32))
+                    robust.append(bool(np.isin(row[:3], [0.0, 1.0, -1.0]).all()))
+                break
+    for k in range(scene.n_spheres):  # centre + (r, 0, 0): on the sphere exactly when the sum is exact
+        c, r = scene.spheres[k, 12:15], scene.spheres[k, 38]
+        P = (c + np.array([r, 0, 0], np.float32)).astype(np.float32)
+        for sgn in (1.0, -1.0):
+            o.append(P)
+            d.append(np.array([sgn * .6, .8, 0], np.float32))
+            robust.append(bool(r == 1.0 and (c == np.round(c * 2) / 2).all()))
+    o, d, robust = np.array(o, np.float32), np.array(d, np.float32), np.array(robust)
+    assert len(o) >= 12 and robust.sum() >= 8
+    want = OracleLib("oracle").create(scene, 0).trace(o, d)
+    assert (want["t"] == 0).sum() >= 8  # the construction really produced zero-distance hits
+    with HipRenderer(scene, 8, 8, strict=True) as r:
+        strict = r.kat_trace(o, d)
+    assert np.array_equal(strict["idx"], want["idx"]) and np.array_equal(strict["t"].view(np.uint32), want["t"].view(np.uint32))
+    with HipRenderer(scene, 8, 8) as r:
+        fast = r.kat_trace(o, d)
+    zero = (want["t"] == 0) & robust
+    assert zero.sum() >= 6
+    assert np.array_equal(fast["idx"][zero], want["idx"][zero]), (fast["idx"], want["idx"], robust)
+    assert (fast["t"][zero] == 0).all()

@@ -72,3 +72,18 @@ def test_layout_matches_library_sizes():
     # balance: no rank owns more than 1 % above the mean
     px = [lay.owned_pixels(r) for r in range(8)]
     assert max(px) <= 1.01 * (1920 * 1080 / 8)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE must start the two ranks itself (a child torch.distributed.run) and
+    pass their exit code on. Without a GPU every rank stops at "needs a GPU" (the backend has no CPU path): seeing that
+    message from a process that has RANK set proves the launch happened; the non-zero code proves it is propagated."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_multi_rank_gpu.py")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1",
+                        "--warmup", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert p.returncode != 0
+    assert "bench.py needs a GPU" in p.stderr and "--nproc-per-node" not in p.stdout
+    assert p.stderr.count("bench.py needs a GPU") >= 2 or "local_rank: 1" in p.stderr or "rank      : 1" in p.stderr

@@ -2,7 +2,7 @@ import re, collections, sys, subprocess
 src='kajo_amd/csrc/kernel_fast.hip' if len(sys.argv)<2 else sys.argv[1]
 kern='kajo_render_fast' if len(sys.argv)<3 else sys.argv[2]
 extra=sys.argv[3:] 
-subprocess.run(['hipcc','--offload-arch=gfx950','-O3','-ffp-contract=fast','-fno-slp-vectorize','-std=c++17','-gline-tables-only','-Iinclude','-Ikajo_amd/csrc','-S','--cuda-device-only',src,'-o','/tmp/t/blk.s']+extra,check=True,stderr=subprocess.DEVNULL)
+subprocess.run(['hipcc','--offload-arch=gfx950','-O3',('-ffp-contract=off' if 'strict' in src else '-ffp-contract=fast'),'-fno-slp-vectorize','-std=c++17','-gline-tables-only','-Iinclude','-Ikajo_amd/csrc','-S','--cuda-device-only',src,'-o','/tmp/t/blk.s']+extra,check=True,stderr=subprocess.DEVNULL)
 lines=open('/tmp/t/blk.s').read().split('\n')
 start=[i for i,l in enumerate(lines) if l.startswith(kern+':')][0]
 end=[i for i,l in enumerate(lines) if i>start and l.startswith('.Lfunc_end')][0]

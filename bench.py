@@ -49,7 +49,7 @@ PEAK_HBM_GBS = 8000.0
 WORKLOADS = {
     # name: (W, H, passes per frame, passes fused per kernel launch, label)
     "c2": (1920, 1080, 16, 16, "BASELINE configs[1]"),
-    "c3": (3840, 2160, 64, 32, "BASELINE configs[2]"),
+    "c3": (3840, 2160, 64, 64, "BASELINE configs[2]"),
 }
 PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc runs
 

@@ -353,8 +353,13 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     size_t gridBytes = 0;
     if (st.gridEnabled) {
         gridBytes = (st.gridCellStart.size() + st.gridItems.size()) * sizeof(uint32_t);
-        // four 4-wave workgroups per CU share 160 KiB: hot records + grid + mailboxes must stay under 40 KiB
-        v.grid.inLds = hotBytes + gridBytes + 4 * 4096 <= 40 * 1024;
+        // The DDA reads a cell record and an item per step, each a dependent load: from LDS that is ~64 cycles, from L2
+        // ~500 (measured on the 1000-sphere scene: the walk was latency-bound). Three 4-wave workgroups per CU share
+        // 160 KiB (3 or 4 waves per SIMD run the render kernels equally fast): hot records + grid + mailboxes <= 53 KiB.
+        size_t gridLimit = 53 * 1024;
+        if (const char* e = std::getenv("KAJO_GRID_LDS_LIMIT")) // tuning knob, bytes
+            gridLimit = (size_t)std::atol(e);
+        v.grid.inLds = hotBytes + gridBytes + 4 * 4096 <= gridLimit;
         if (!v.grid.inLds)
             gridBytes = 0;
     }

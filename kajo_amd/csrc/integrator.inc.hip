@@ -590,8 +590,10 @@ KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 b
         float r = ksqrt(u);
 #if KAJO_STRICT
         float phi = (float)((double)(v * 2) * kPi);
-        float x = r * kajo_cosf(phi);
-        float y = r * kajo_sinf(phi);
+        float sphi, cphi;
+        kajo_sincosf(phi, &sphi, &cphi);
+        float x = r * cphi;
+        float y = r * sphi;
         float z = __builtin_sqrtf(fmaxf(0.0f, 1.0f - u));
         pdf = (float)((double)z * kInvPi);
 #else
@@ -607,8 +609,11 @@ KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 b
 #if KAJO_STRICT
     float a = kajo_acosf(kajo_powf(u, 1.0f / (exponent + 1)));
     float phi = (float)(2 * kPi * (double)v);
-    s = f3(kajo_sinf(a) * kajo_cosf(phi), kajo_sinf(a) * kajo_sinf(phi), kajo_cosf(a));
-    pdf = (float)((double)(exponent + 1) / (2 * kPi) * (double)kajo_powf(kajo_cosf(a), exponent));
+    float sa, ca, sphi, cphi;
+    kajo_sincosf(a, &sa, &ca);
+    kajo_sincosf(phi, &sphi, &cphi);
+    s = f3(sa * cphi, sa * sphi, ca);
+    pdf = (float)((double)(exponent + 1) / (2 * kPi) * (double)kajo_powf(ca, exponent));
 #else
     // cos(acos(c)) = c and sin(acos(c)) = sqrt(1 - c^2): no inverse trigonometry needed
     const float lca = __builtin_amdgcn_logf(u) * krcp(exponent + 1); // log2 of the sampled cosine
@@ -690,8 +695,10 @@ KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
     float s1 = unit(g0), s2 = unit(g1), s3 = unit(g2);
 #if KAJO_STRICT
     float ang = (float)(2 * kPi * (double)s2);
-    float x = radius * __builtin_sqrtf(s1) * kajo_cosf(ang);
-    float y = radius * __builtin_sqrtf(s1) * kajo_sinf(ang);
+    float sang, cang;
+    kajo_sincosf(ang, &sang, &cang);
+    float x = radius * __builtin_sqrtf(s1) * cang;
+    float y = radius * __builtin_sqrtf(s1) * sang;
     float z = __builtin_sqrtf(radius * radius - x * x - y * y) * kajo_sinf((float)(kPi * (double)(s3 - .5f)));
 #else
     float rs = radius * ksqrt(s1);
@@ -1067,7 +1074,17 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             // advanced with a zero light pdf when the direction was sampled (0 + p == p exactly); only a ray
             // that lands on a light other than the vertex it left needs the MIS denominator pL + p.
             if (pendBsdf) {
-                if (hit.id > np && hit.id != vId && lds.material[hit.id - 1].isLight) {
+                // (A light that is a pure emitter -- no diffuse, specular or transparent colour, pRR == 0 -- ends every path
+                // that reaches it, and a path that arrives over a BSDF-sampled segment collects no emission there
+                // (Shader.cpp:121,212): its throughput is never used again, so the MIS correction is skipped. STRICT
+                // keeps it when the throughput is not finite: NaN * 0 must stay NaN.)
+                const DMaterial& hm = lds.material[hit.id > 0 ? hit.id - 1 : 0];
+#if KAJO_STRICT
+                const bool weightMatters = hm.pRR != 0.0f || !(__builtin_fabsf(T.x) < __builtin_inff() && __builtin_fabsf(T.y) < __builtin_inff() && __builtin_fabsf(T.z) < __builtin_inff());
+#else
+                const bool weightMatters = hm.pRR != 0.0f;
+#endif
+                if (hit.id > np && hit.id != vId && hm.isLight && weightMatters) {
                     const DSphereCold& lc = lds.sphereCold[hit.id - 1 - np];
 #if KAJO_STRICT
                     const float pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));

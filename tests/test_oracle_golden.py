@@ -223,3 +223,23 @@ def test_single_path_replay(O, scenes):
         log, one = debug_path(h, W, H, S, x, y, 7)
         assert np.array_equal(one.view(np.uint32), rgb[7].view(np.uint32))
         assert log.shape[1] == 4 and int(log[0, 0]) in (1, 0) or len(log) == 0
+
+
+def test_full_size_workload_crops(O, golden, scenes):
+    """frames2.npz (round 2): crops of BASELINE configs[1] at its own size and pass count (1920 x 1080, 16 passes) and of
+    configs[0] at 256 x 256, rendered by the COMPILED REFERENCE. The oracle renders the same rectangles: most pixels equal
+    the reference's -O2 build bit for bit (the rest differ in the last place: the throughput is associated differently),
+    all of them within the reference-vs-reference floor."""
+    z = golden.frames2
+    seed = int(z["seed"])
+    for name, key, W, H, S, passes, depth, ncrops in (("c2_1080p", "spheres_a169", 1920, 1080, 32, 16, 8, 3), ("c1_256", "spheres_a1", 256, 256, 16, 1, 1, 6)):
+        for math in (0, 1):
+            h = O.create(scenes[key], math)
+            for k, (x, y, w, hh) in enumerate(z[name + "/crops"][:ncrops]):
+                a = h.render(W, H, S=S, passes=passes, seed=seed, depth_limit=depth, rect=(int(x), int(y), int(w), int(hh)))[y:y + hh, x:x + w, :3]
+                rs, rf = z[name + "/rgb_crops_strict"][k], z[name + "/rgb_crops_fast"][k]
+                m = np.isfinite(a) & np.isfinite(rs)
+                assert np.median(np.abs(a - rs)[m]) / passes <= 1e-6
+                assert np.mean((a.view(np.uint32) == rs.view(np.uint32)).all(-1)) >= (0.4 if passes > 1 else 0.85), (name, math, k)
+                s, floor = frame_stats(a / passes, rs / passes), frame_stats(rs / passes, rf / passes)
+                assert s["clamped_rmse"] <= max(1e-4, 1.25 * floor["clamped_rmse"]), (name, math, k, s, floor)

@@ -53,7 +53,7 @@ def crops_for(scene, W, H, limit=10):
     return crops[:limit]
 
 
-def check_workload(scene, W, H, S, passes, depth, limit=10, fast_px_budget=0.004, ppl=0, slack=1.5, floor_crops=None):
+def check_workload(scene, W, H, S, passes, depth, limit=10, fast_px_budget=0.004, ppl=0, slack=1.5):
     crops = crops_for(scene, W, H, limit)
     assert len(crops) >= 8
     O = OracleLib("oracle")
@@ -65,7 +65,21 @@ def check_workload(scene, W, H, S, passes, depth, limit=10, fast_px_budget=0.004
     # where the compiled reference travelled with the snapshot, its two builds (-O2 / fast-math) render every crop too:
     # what they differ by is the floor no implementation with other roundings can get under (an emitter's silhouette:
     # every path that flips there moves its pixel by emission / (25 * passes))
-    refs = [OracleLib(k).create(scene) for k in ("ref", "ref_strict")] if available("ref") and available("ref_strict") else None
+    refs = available("ref") and available("ref_strict")
+    floors = {}
+    if refs:  # the reference renders one rectangle per thread (its harness is single-threaded; ctypes releases the GIL)
+        from concurrent.futures import ThreadPoolExecutor
+        libs = {k: OracleLib(k) for k in ("ref", "ref_strict")}
+
+        def ref_crop(job):
+            k, (name, x, y, w, h) = job
+            q = libs[k].create(scene)
+            a = q.render(W, H, S=S, passes=passes, seed=SEED, depth_limit=depth, rect=(x, y, w, h))[y:y + h, x:x + w, :3] / passes
+            q.close()
+            return (k, name), a
+
+        with ThreadPoolExecutor(THREADS) as ex:
+            floors = dict(ex.map(ref_crop, [(k, c) for c in crops for k in ("ref", "ref_strict")]))
     report = []
     for name, x, y, w, h in crops:
         rect = (x, y, w, h)
@@ -80,8 +94,8 @@ def check_workload(scene, W, H, S, passes, depth, limit=10, fast_px_budget=0.004
         cl = np.where(m, np.clip(gf, 0, 1) - np.clip(wf, 0, 1), 0.0)
         off = int((np.abs(cl).max(-1) > 1e-3).sum())
         floor = (0.0, 0.0, 0.0, 0)
-        if refs and (floor_crops is None or len(report) < floor_crops):
-            ra, rb = (q.render(W, H, S=S, passes=passes, seed=SEED, depth_limit=depth, rect=rect)[y:y + h, x:x + w, :3] / passes for q in refs)
+        if refs:
+            ra, rb = floors[("ref", name)], floors[("ref_strict", name)]
             mm = np.isfinite(ra) & np.isfinite(rb)
             dd = np.abs(ra - rb)[mm]
             cc = np.where(mm, np.clip(ra, 0, 1) - np.clip(rb, 0, 1), 0.0)
@@ -90,9 +104,6 @@ def check_workload(scene, W, H, S, passes, depth, limit=10, fast_px_budget=0.004
     # FAST: SURVEY section 8c tolerances on every crop (median 1e-5, p99 2e-3, clamped RMSE 1e-3) ...
     # (or 1.5 x the reference's own two-build difference on that crop, whichever is larger)
     slack = slack if refs else 2.5
-    if refs and floor_crops is not None:  # the reference (single-threaded here) rendered only the first crops: their worst figures stand for all
-        worst = tuple(max(r[6][k] for r in report[:floor_crops]) for k in range(4))
-        report = [r[:6] + (worst,) for r in report]
     for name, med, p99, rmse, off, nonfinite, floor in report:
         tol = [max(t, slack * f) if refs else slack * t for t, f in zip((1e-5, 2e-3, 1e-3), floor)]
         assert med <= tol[0] and p99 <= tol[1] and rmse <= tol[2], (scene.name, name, (med, p99, rmse), floor)
@@ -138,7 +149,7 @@ def test_configs4_stress_1000_spheres_1080p(scenes):
     # two passes: the oracle and the reference walk all 1006 primitives per ray (CPU minutes at more). 50 paths per pixel
     # among 1000 small Phong / diffuse spheres and 16 lights leave single flipped paths visible: measured 1.2-1.8 x the
     # reference's own two-build difference (as in test_hip_edge_cases.py), hence the wider slack
-    check_workload(sc, 1920, 1080, 32, 2, 8, limit=8, fast_px_budget=0.01, ppl=2, slack=2.5, floor_crops=2)
+    check_workload(sc, 1920, 1080, 32, 2, 8, limit=8, fast_px_budget=0.01, ppl=2, slack=2.5)
 
 
 def test_configs0_c1_full_size_against_the_reference(scenes, golden):
@@ -154,13 +165,17 @@ def test_configs0_c1_full_size_against_the_reference(scenes, golden):
         for tag in ("strict", "fast"):
             want = z["c1_256/argb8_" + tag]
             ch = lambda a, s: ((a >> s) & 255).astype(np.int32)
-            dmax = max(np.abs(ch(argb, s) - ch(want, s)) for s in (0, 8, 16))
+            dmax = np.maximum.reduce([np.abs(ch(argb, s) - ch(want, s)) for s in (0, 8, 16)])
             assert np.mean(dmax > 1) <= 0.002, (strict, tag, float(np.mean(dmax > 1)))
         for k, (x, y, w, h) in enumerate(z["c1_256/crops"]):
             ref = z["c1_256/rgb_crops_strict"][k]
             g = acc[y:y + h, x:x + w, :3]
             m = np.isfinite(g) & np.isfinite(ref)
-            assert np.median(np.abs(g - ref)[m]) <= 1e-5 and np.percentile(np.abs(g - ref)[m], 99) <= 2e-3
+            reff = z["c1_256/rgb_crops_fast"][k]
+            floor99 = np.percentile(np.abs(ref - reff)[np.isfinite(ref) & np.isfinite(reff)], 99)  # the reference's two builds
+            # (the median relative to the value where that exceeds 1: the emitter's pixels hold 445, whose last place is 3e-5)
+            assert np.median((np.abs(g - ref) / np.maximum(1.0, np.abs(ref)))[m]) <= 1e-5
+            assert np.percentile(np.abs(g - ref)[m], 99) <= max(2e-3, 1.5 * floor99)
             if strict:
                 assert np.mean((g.view(np.uint32) == ref.view(np.uint32)).all(-1)) >= 0.9
         with HipRenderer(sc, 64, 64, spp=32, depth_limit=8, seed=seed, strict=strict) as r:

@@ -110,6 +110,7 @@ struct KajoHip
                                 // independently (measured +2.3 % over 4-wave groups)
     int passesDone = 0;
     size_t ldsBytes = 0, hotBytes = 0;
+    int stealWindow = 4; // render_args.h; 1 when a large scene needs the LDS for its grid
     int coldInLds = 1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // kernel timing
     std::vector<hipEvent_t> eventPool;
@@ -315,7 +316,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     CREATE_TRY(upload(st.light, &v.light, h->sceneBuffers));
     {
         const uint32_t* cellStart = nullptr;
-        const uint32_t* items = nullptr;
+        const uint16_t* items = nullptr;
         CREATE_TRY(upload(st.gridCellStart, &cellStart, h->sceneBuffers));
         CREATE_TRY(upload(st.gridItems, &items, h->sceneBuffers));
         v.grid.enabled = st.gridEnabled;
@@ -352,14 +353,21 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
                              (size_t)v.nLights * 4;
     size_t gridBytes = 0;
     if (st.gridEnabled) {
-        gridBytes = (st.gridCellStart.size() + st.gridItems.size()) * sizeof(uint32_t);
-        // The DDA reads a cell record and an item per step, each a dependent load: from LDS that is ~64 cycles, from L2
-        // ~500 (measured on the 1000-sphere scene: the walk was latency-bound). Three 4-wave workgroups per CU share
-        // 160 KiB (3 or 4 waves per SIMD run the render kernels equally fast): hot records + grid + mailboxes <= 53 KiB.
-        size_t gridLimit = 53 * 1024;
+        gridBytes = ((st.gridCellStart.size() * sizeof(uint32_t) + st.gridItems.size() * sizeof(uint16_t)) + 15) & ~(size_t)15;
+        // The DDA reads a cell record and an item per step, each a dependent load: ~64 cycles from LDS, ~500 from L2. But the
+        // walk is latency-bound and wants its four workgroups per CU (measured on the 1000-sphere scene: the grid in LDS at
+        // three workgroups per CU is 12 % SLOWER than the grid in L2 at four), so the grid moves into LDS only while hot
+        // records + grid + mailboxes stay within 40 KiB -- with the mailboxes shrunk to a one-pass steal window if need be.
+        size_t gridLimit = 40 * 1024;
         if (const char* e = std::getenv("KAJO_GRID_LDS_LIMIT")) // tuning knob, bytes
             gridLimit = (size_t)std::atol(e);
-        v.grid.inLds = hotBytes + gridBytes + 4 * 4096 <= gridLimit;
+        for (int window : {4, 2, 1}) {
+            if (hotBytes + gridBytes + (size_t)4 * 64 * window * 16 <= gridLimit) {
+                v.grid.inLds = 1;
+                h->stealWindow = window;
+                break;
+            }
+        }
         if (!v.grid.inLds)
             gridBytes = 0;
     }
@@ -367,7 +375,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     h->coldInLds = hotBytes + coldBytes <= 40 * 1024 && !st.gridEnabled;
     h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0) + gridBytes;
     // scene copy + the pass-stealing mailboxes of a 4-wave workgroup (64 lanes x 4 passes x float4 per wave) must fit a CU
-    if (((h->ldsBytes + 15) & ~(size_t)15) + 4 * 4096 > 160 * 1024) {
+    if (((h->ldsBytes + 15) & ~(size_t)15) + (size_t)4 * 64 * h->stealWindow * 16 > 160 * 1024) {
         destroy(h);
         return fail(KAJO_E_INVALID, "scene exceeds the LDS staging limit: hot records + 16 KiB of mailboxes must fit 160 KiB");
     }
@@ -409,7 +417,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         }
     }
     {
-        const size_t ldsTotal = ((h->ldsBytes + 15) & ~(size_t)15) + (size_t)h->wavesPerBlock * 64 * 4 * 16;
+        const size_t ldsTotal = ((h->ldsBytes + 15) & ~(size_t)15) + (size_t)h->wavesPerBlock * 64 * h->stealWindow * 16;
         if (ldsTotal > 48 * 1024) {
             CREATE_TRY((hipError_t)(h->strict() ? kajo_render_strict_set_lds(h->coldInLds, ldsTotal)
                                                 : kajo_render_fast_set_lds(h->coldInLds, ldsTotal)));
@@ -479,13 +487,14 @@ int kajo_hip_render(kajo_hip_t h, int passes)
     a.nTilesOwned = h->nTilesOwned;
     a.counters = h->counters;
     a.mailboxOffset = (uint32_t)((h->ldsBytes + 15) & ~(size_t)15);
+    a.stealWindow = h->stealWindow;
 
     const unsigned block = 64 * h->wavesPerBlock;
     const unsigned grid = h->gridBlocks;
     a.blockOrder = h->orderValid ? h->blockOrder : nullptr;
     a.waveTrips = (h->waveTrips && !h->orderValid) ? h->waveTrips : nullptr; // measure once, on the first launch
     // scene copy + one mailbox (64 lanes x 4 passes x float4) per wave of the workgroup
-    const size_t ldsTotal = a.mailboxOffset + (size_t)h->wavesPerBlock * 64 * 4 * 16;
+    const size_t ldsTotal = a.mailboxOffset + (size_t)h->wavesPerBlock * 64 * h->stealWindow * 16;
     const int perLaunch = p.passesPerLaunch > 0 ? p.passesPerLaunch : 16;
     int left = passes;
     while (left > 0) {
@@ -786,6 +795,7 @@ int kajo_hip_kat_shade(kajo_hip_t h, int n, const float* origins, const float* d
     a.katRgb = static_cast<float*>(dRgb.p);
     a.katFinal = static_cast<uint64_t*>(dFinal.p);
     a.katCount = n;
+    a.stealWindow = 1;
     const unsigned grid = (unsigned)((n + 255) / 256);
     hipError_t le = (hipError_t)(h->strict() ? kajo_kat_shade_strict_launch(&a, grid, h->hotBytes, h->stream)
                                              : kajo_kat_shade_fast_launch(&a, grid, h->hotBytes, h->stream));

@@ -74,7 +74,7 @@ struct DGrid
     float bmin[3], bmax[3];
     float cell[3], invCell[3];
     const uint32_t* cellStart; // [dim.x * dim.y * dim.z + 1]
-    const uint32_t* items;     // sphere indices, ascending within a cell
+    const uint16_t* items;     // sphere indices (16 bits: the hot records of 65536 spheres would not fit LDS anyway), ascending within a cell
     int32_t nCells, nItems;
     int32_t inLds;             // the two arrays are staged into LDS behind the hot records
 };

@@ -178,7 +178,7 @@ struct LdsScene
     const DMaterial* material;
     const int32_t* light;
     const uint32_t* gridCellStart; // LDS copy when it fits (DGrid.inLds), else the global arrays
-    const uint32_t* gridItems;
+    const uint16_t* gridItems;
 };
 
 // One sphere of Raytracer.cpp:21-72 up to (not including) processIntersection: returns false when the
@@ -223,6 +223,12 @@ KDEV bool sphereCandidate(const DSceneView& sc, const LdsScene& lds, int i, F3 O
     // roots q/a and c/q, sorted
     float b = 2 * h;
     float discr = b * b - 4 * a * c;
+    // The correctly rounded square root and the two divisions are 38 of this test's 62 instructions; a wave whose rays ALL
+    // miss the sphere's line (primary rays of an 8x8 block mostly do) skips them. No lane's result depends on it.
+    if (__builtin_amdgcn_ballot_w64(!(discr < 0.0f)) == 0ull) {
+        ts = th = 0.0f;
+        return false;
+    }
     float sq = ksqrt(discr);
     float q = (b < 0.0f) ? (-b - sq) * .5f : (-b + sq) * .5f;
     float t0 = kdiv(q, a);
@@ -274,15 +280,21 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
     const float dx = d.x == 0.0f ? inf : g.cell[0] * __builtin_fabsf(ix_);
     const float dy = d.y == 0.0f ? inf : g.cell[1] * __builtin_fabsf(iy_);
     const float dz = d.z == 0.0f ? inf : g.cell[2] * __builtin_fabsf(iz_);
+    // The walk is one loop without inner branches on the axis: the cell is a linear index moved by a per-axis stride, the
+    // cells left before the grid ends are counted per axis, and the axis to cross is chosen with selects (the three-way
+    // branch of a textbook DDA runs all three arms in a wave of incoherent rays).
+    int cell = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+    const int strideX = sx, strideY = sy * g.dim[0], strideZ = sz * g.dim[0] * g.dim[1];
+    int leftX = sx > 0 ? g.dim[0] - 1 - cx : cx, leftY = sy > 0 ? g.dim[1] - 1 - cy : cy, leftZ = sz > 0 ? g.dim[2] - 1 - cz : cz;
     for (int guard = g.dim[0] + g.dim[1] + g.dim[2] + 3; guard > 0; guard--) {
-        const int cell = (cz * g.dim[1] + cy) * g.dim[0] + cx;
+        const uint32_t k0 = lds.gridCellStart[cell];
         const uint32_t e = lds.gridCellStart[cell + 1];
 #if !KAJO_STRICT
         if (sc.allTranslated) {
             // (centre, radius) spheres with the bookkeeping of the brute-force walk: the smaller non-negative root is
             // the smaller bit pattern, "exists, not behind, closer" one unsigned compare (plus the tie rule)
             uint32_t kMax = __builtin_bit_cast(uint32_t, tMax);
-            for (uint32_t k = lds.gridCellStart[cell]; k < e; k++) {
+            for (uint32_t k = k0; k < e; k++) {
                 const int i = (int)lds.gridItems[k];
                 const DFloat4 s = lds.sphereHot[i];
                 F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
@@ -300,7 +312,7 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
             bestT0 = tMax;
         } else
 #endif
-        for (uint32_t k = lds.gridCellStart[cell]; k < e; k++) {
+        for (uint32_t k = k0; k < e; k++) {
             const int i = (int)lds.gridItems[k];
             float ts, th;
             const bool valid = sphereCandidate(sc, lds, i, O, d, aT, iaT, ts, th);
@@ -313,22 +325,17 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
         const float tExit = fminf(nx, fminf(ny, nz));
         if (tMax < tExit) // nothing in a later cell can be closer (spheres are registered with a margin)
             break;
-        if (nx <= ny && nx <= nz) {
-            cx += sx;
-            nx += dx;
-            if (cx < 0 || cx >= g.dim[0])
-                break;
-        } else if (ny <= nz) {
-            cy += sy;
-            ny += dy;
-            if (cy < 0 || cy >= g.dim[1])
-                break;
-        } else {
-            cz += sz;
-            nz += dz;
-            if (cz < 0 || cz >= g.dim[2])
-                break;
-        }
+        const bool stepX = nx <= ny && nx <= nz, stepY = !stepX && ny <= nz;
+        const int left = stepX ? leftX : (stepY ? leftY : leftZ);
+        if (left == 0) // the ray leaves the grid
+            break;
+        cell += stepX ? strideX : (stepY ? strideY : strideZ);
+        leftX -= stepX ? 1 : 0;
+        leftY -= stepY ? 1 : 0;
+        leftZ -= (stepX || stepY) ? 0 : 1;
+        nx += stepX ? dx : 0.0f;
+        ny += stepY ? dy : 0.0f;
+        nz += (stepX || stepY) ? 0.0f : dz;
     }
 }
 
@@ -374,6 +381,15 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
         const float det = lds.planeDet[i];
         float denom = r.x * d.x + r.y * d.y + r.z * d.z;
         float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w * 1.0f;
+#if KAJO_STRICT
+        // The correctly rounded division is a third of this test. A ray that is parallel to the plane, or that has the plane
+        // behind it (t = -oy / denom negative: oy and denom of one sign, far enough from underflow that the quotient cannot
+        // round to -0), is rejected whatever t is: a wave whose rays are all of that kind skips the division.
+        const bool behind = ((__builtin_bit_cast(uint32_t, oy) ^ __builtin_bit_cast(uint32_t, denom)) >> 31) == 0u &&
+                            __builtin_fabsf(oy) > 0x1p-60f && __builtin_fabsf(denom) < 0x1p60f;
+        if (__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(denom) < kFltEpsilon) && !behind) == 0ull)
+            continue;
+#endif
         float t = kdiv(-oy, denom);
         float ts = t * det;
         bool ok = !(__builtin_fabsf(denom) < kFltEpsilon) && !(t < 0.0f) && !(ts > tMax || ts < 0.0f);
@@ -724,9 +740,8 @@ enum : int
 
 } // namespace
 
-#ifndef KAJO_STEAL_WINDOW
-#define KAJO_STEAL_WINDOW 4 // passes at the end of a launch that an idle lane may take over
-#endif
+// passes at the end of a launch that an idle lane may take over: RenderArgs::stealWindow, at most 4 (64 lanes x 4 float4 = 4 KiB
+// of mailbox per wave; large scenes that need the LDS for their grid run with 1)
 
 #ifndef KAJO_WAVES_PER_SIMD
 #define KAJO_WAVES_PER_SIMD 4 // register budget: 512 / 4 = 128 VGPRs per lane
@@ -794,7 +809,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     if (!COLD_LDS && sc.grid.enabled && sc.grid.inLds) {
         // the DDA reads two cell offsets per step: from LDS that is ~64 cycles, from L2 ~500
         uint32_t* cs = reinterpret_cast<uint32_t*>(ldsSphereOff + ns);
-        uint32_t* it = cs + sc.grid.nCells + 1;
+        uint16_t* it = reinterpret_cast<uint16_t*>(cs + sc.grid.nCells + 1);
         for (int i = threadIdx.x; i <= sc.grid.nCells; i += blockDim.x)
             cs[i] = sc.grid.cellStart[i];
         for (int i = threadIdx.x; i < sc.grid.nItems; i += blockDim.x)
@@ -822,8 +837,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
 
-    // per-wave mailbox for taken-over passes: [lane][KAJO_STEAL_WINDOW] float4, behind the scene copy
-    DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.mailboxOffset) + (threadIdx.x >> 6) * (64 * KAJO_STEAL_WINDOW);
+    // per-wave mailbox for taken-over passes: [lane][stealWindow] float4, behind the scene copy
+    const int stealWindow = args.stealWindow;
+    DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.mailboxOffset) + (threadIdx.x >> 6) * (64 * stealWindow);
 
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;
@@ -882,12 +898,12 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // streams, its sum enters the pixel's total as one term), so a lane that has finished its own pixel
     // takes over the LAST not-yet-started pass of a lane that still has several to go, renders it, and
     // leaves radiance / S in a mailbox in LDS; the owner adds the mailbox terms after its own passes, in
-    // pass order -- the float sums are formed exactly as without stealing. Only the last KAJO_STEAL_WINDOW
+    // pass order -- the float sums are formed exactly as without stealing. Only the last `stealWindow`
     // passes of a launch can be given away (that is all the imbalance there is, and bounds the mailbox).
     int ownPass = firstMine; // next pass of the lane's own pixel
     int myEnd = inImage ? lastPass : firstMine; // own passes [ownPass, myEnd); shrinks when one is taken over
     int stolenFrom = -1;          // lane whose pass is being rendered, or -1
-    const int stealBase = lastPass - KAJO_STEAL_WINDOW > firstMine ? lastPass - KAJO_STEAL_WINDOW : firstMine;
+    const int stealBase = lastPass - stealWindow > firstMine ? lastPass - stealWindow : firstMine;
     int sampleX = 0, sampleY = 0;
     F3 radiance = f3(0.0f, 0.0f, 0.0f); // sum over the pixel's samples of this pass
     Rng rng{0, 0};
@@ -980,7 +996,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     else
                         ownPass++;
                 } else if (stolenFrom >= 0) {
-                    mailbox[stolenFrom * KAJO_STEAL_WINDOW + (pass - stealBase)] = DFloat4{term.x, term.y, term.z, 0.0f};
+                    mailbox[stolenFrom * stealWindow + (pass - stealBase)] = DFloat4{term.x, term.y, term.z, 0.0f};
                     stolenFrom = -1;
                 } else {
                     total = total + term;
@@ -1261,7 +1277,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     } else if (!KAT && inImage) {
         // passes of this pixel that other lanes rendered, in pass order
         for (int p = myEnd; p < lastPass; p++) {
-            const DFloat4 t = mailbox[lane * KAJO_STEAL_WINDOW + (p - stealBase)];
+            const DFloat4 t = mailbox[lane * stealWindow + (p - stealBase)];
             total = total + f3(t.x, t.y, t.z);
         }
         reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);

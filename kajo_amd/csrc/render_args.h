@@ -21,6 +21,7 @@ struct RenderArgs
     int32_t tileIndex, tileCount, nTilesOwned;
     unsigned long long* counters; // [0] traversals, [1] vertices, [2] lane slots; may be null
     uint32_t mailboxOffset;       // byte offset of the pass-stealing mailboxes in dynamic LDS (16-byte aligned)
+    int32_t stealWindow;          // passes at the end of a launch an idle lane may take over (1..KAJO_STEAL_WINDOW_MAX): sizes the mailboxes
     // Launch-order feedback: blocks are dispatched in blockIdx order; the host sorts them by the cost the
     // previous launch measured (longest first) so that the launch does not end on its most expensive
     // workgroups. Pure scheduling: the buffer slot of a pixel does not depend on it.

@@ -183,7 +183,7 @@ void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
 {
     out.gridEnabled = false;
     const int n = s.nSpheres;
-    if (n < gridMinSpheres || gridMinSpheres <= 0)
+    if (n < gridMinSpheres || gridMinSpheres <= 0 || n > 65535) // (cell lists hold 16-bit sphere indices)
         return;
     // The walk compares the reported distances t * determinant (Raytracer.cpp:71,97) with WORLD-space cell
     // boundaries, which is only sound when the two agree: every sphere determinant exactly 1 (t itself is the world-space
@@ -245,7 +245,7 @@ void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
                         if (pass == 0)
                             count[c + 1]++;
                         else
-                            out.gridItems[count[c]++] = (uint32_t)i;
+                            out.gridItems[count[c]++] = (uint16_t)i;
                     }
         }
         if (pass == 0) {

@@ -28,7 +28,8 @@ struct StagedScene
     bool gridEnabled = false;
     int gridDim[3] = {0, 0, 0};
     float gridMin[3], gridMax[3], gridCell[3];
-    std::vector<uint32_t> gridCellStart, gridItems;
+    std::vector<uint32_t> gridCellStart;
+    std::vector<uint16_t> gridItems;
 };
 
 void stageScene(const KajoScene& scene, StagedScene& out, int gridMinSpheres = 48);

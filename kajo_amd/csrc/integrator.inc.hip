@@ -59,9 +59,16 @@ KDEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 
 // ---- numerics policy ------------------------------------------------------------------
 #if KAJO_STRICT
+#ifdef KAJO_X_APPROX_DIVSQRT
+// TIMING EXPERIMENT ONLY (not bit-exact): what the correctly rounded divisions and square roots cost the STRICT kernels
+KDEV float kdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+KDEV float ksqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+KDEV float krcp(float a) { return __builtin_amdgcn_rcpf(a); }
+#else
 KDEV float kdiv(float a, float b) { return a / b; }
 KDEV float ksqrt(float a) { return __builtin_sqrtf(a); }
 KDEV float krcp(float a) { return 1.0f / a; }
+#endif
 KDEV float kpow(float x, float y) { return kajo_powf(x, y); }
 #else
 // FAST: the hardware's 1-ulp reciprocal, square root and reciprocal square root (profiles/r01_hwmath_accuracy.txt).
@@ -103,7 +110,9 @@ KDEV float kmax0(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 KDEV F3 normalize(F3 a)
 {
     float sqr = a.x * a.x + a.y * a.y + a.z * a.z;
-#if KAJO_STRICT
+#if KAJO_STRICT && defined(KAJO_X_APPROX_DIVSQRT)
+    return a * __builtin_amdgcn_rsqf(sqr);
+#elif KAJO_STRICT
     return a * (1.0f / __builtin_sqrtf(sqr)); // glm: x * inversesqrt(dot), inversesqrt = 1 / sqrt
 #else
     return a * krsq(sqr);

@@ -1,5 +1,10 @@
-import sys, os, csv, glob, collections
+"""Summarise rocprofv3 --pmc passes (tools/pmc.sh) per kernel: raw counters per launch, the derived figures bench.py
+quotes (HBM bytes with the gfx950 FETCH_SIZE correction, executed FP32 work, VALU lane utilisation), and
+<dir>/counters.json in the layout of profiles/r02_counters.json.
+usage: pmc_summary.py <dir> [workload-name]"""
+import sys, os, csv, glob, collections, json
 out = sys.argv[1]
+workload = sys.argv[2] if len(sys.argv) > 2 else 'c2'
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.defaultdict(lambda: collections.defaultdict(int))
 for f in glob.glob(os.path.join(out, '*', '*', '*counter_collection.csv')):
@@ -7,8 +12,25 @@ for f in glob.glob(os.path.join(out, '*', '*', '*counter_collection.csv')):
         k = row['Kernel_Name']
         agg[k][row['Counter_Name']] += float(row['Counter_Value'])
         cnt[k][row['Counter_Name']] += 1
-for k in agg:
+res = {}
+for k in sorted(agg):
     if 'kajo_render' not in k: continue
     print('kernel', k)
-    for c in sorted(agg[k]):
-        print('  %-28s per-launch %.6g  (launches %d)' % (c, agg[k][c] / cnt[k][c], cnt[k][c]))
+    per = {c: agg[k][c] / cnt[k][c] for c in agg[k]}
+    for c in sorted(per):
+        print('  %-32s per-launch %.6g  (launches %d)' % (c, per[c], cnt[k][c]))
+    d = {'workload': workload, 'counters_per_launch': per}
+    if 'FETCH_SIZE' in per and 'WRITE_SIZE' in per:
+        # KiB units; on gfx950 FETCH_SIZE counts 64 of every 128 bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM)
+        d['hbm_bytes_per_launch'] = (2 * per['FETCH_SIZE'] + per['WRITE_SIZE']) * 1024
+    if 'SQ_THREAD_CYCLES_VALU' in per and 'SQ_ACTIVE_INST_VALU' in per:
+        d['valu_lane_utilisation'] = per['SQ_THREAD_CYCLES_VALU'] / (per['SQ_ACTIVE_INST_VALU'] * 64)
+    if 'SQ_INSTS_VALU_FLOPS_FP32' in per and 'valu_lane_utilisation' in d:
+        # wave-level FLOP count (an FMA counts 2 per lane-slot x 64 lanes) x the share of lanes that were active
+        d['executed_fp32_flops_per_launch'] = per['SQ_INSTS_VALU_FLOPS_FP32'] * 64 * d['valu_lane_utilisation']
+    if 'SQ_INSTS_SALU' in per and 'SQ_INSTS_VALU' in per:
+        d['salu_per_valu'] = per['SQ_INSTS_SALU'] / per['SQ_INSTS_VALU']
+    for key in ('hbm_bytes_per_launch', 'valu_lane_utilisation', 'executed_fp32_flops_per_launch', 'salu_per_valu'):
+        if key in d: print('  => %-29s %.6g' % (key, d[key]))
+    res[k.split('(')[0]] = d
+json.dump(res, open(os.path.join(out, 'counters.json'), 'w'), indent=1, sort_keys=True)

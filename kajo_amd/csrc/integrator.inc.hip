@@ -148,17 +148,17 @@ KDEV void rngStep(Rng& r)
     r.hi = h + p;
 }
 
-KDEV float lane32(uint32_t bits) { return __fmul_rn((float)(int32_t)bits, 4.6566128730773926e-10f); } // * 2^-31
-
-// uniform in [0,1): x * .5 + .5 with one rounding per operation in BOTH modes, so that a coin
-// never flips merely because FAST contracted the expression (Random.cpp:113)
-KDEV float unit(float g) { return __fadd_rn(__fmul_rn(g, .5f), .5f); }
+// One lane of Random::generate (Random.cpp:41-42) mapped to [0, 1) as every caller does: (float)(int)bits * 2^-31, then
+// x * .5 + .5 (Random.cpp:113, Renderer.cpp:55, Light.cpp:39-41, Random.cpp:79-80). The two multiplications are by
+// powers of two -- exact -- so the value is fl(f * 2^-32 + .5) with f = (float)(int)bits, which ONE fused multiply-add
+// delivers with the same single rounding, in both numerics modes (two instructions instead of four).
+KDEV float unitBits(uint32_t bits) { return __builtin_fmaf((float)(int32_t)bits, 2.3283064365386963e-10f, 0.5f); }
 
 // flipCoin, Random.cpp:111-117
 KDEV bool flipCoin(Rng& r, float probability, float& outProbability)
 {
     rngStep(r);
-    float u = unit(lane32((uint32_t)r.lo));
+    float u = unitBits((uint32_t)r.lo);
     bool v = (probability != 0.0f) && (u <= probability);
     outProbability = v ? probability : __fsub_rn(1.0f, probability);
     return v;
@@ -609,8 +609,8 @@ KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 b
         return R;
     }
     rngStep(rng);
-    float u = unit(lane32((uint32_t)rng.lo));         // .5f * x + .5f
-    float v = unit(lane32((uint32_t)(rng.lo >> 32)));
+    float u = unitBits((uint32_t)rng.lo);         // .5f * x + .5f
+    float v = unitBits((uint32_t)(rng.lo >> 32));
     if (kind == 0) {
         float r = ksqrt(u);
 #if KAJO_STRICT
@@ -716,8 +716,7 @@ KDEV float lightPdf(const DSphereCold& lc, F3 P)
 KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
 {
     rngStep(rng);
-    float g0 = lane32((uint32_t)rng.lo), g1 = lane32((uint32_t)(rng.lo >> 32)), g2 = lane32((uint32_t)rng.hi);
-    float s1 = unit(g0), s2 = unit(g1), s3 = unit(g2);
+    float s1 = unitBits((uint32_t)rng.lo), s2 = unitBits((uint32_t)(rng.lo >> 32)), s3 = unitBits((uint32_t)rng.hi);
 #if KAJO_STRICT
     float ang = (float)(2 * kPi * (double)s2);
     float sang, cang;
@@ -1054,8 +1053,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 rng.lo = (uint64_t)a | ((uint64_t)b << 32);
                 rng.hi = (uint64_t)c | ((uint64_t)dd << 32);
                 rngStep(rng);
-                float offX = unit(lane32((uint32_t)rng.lo));
-                float offY = unit(lane32((uint32_t)(rng.lo >> 32)));
+                float offX = unitBits((uint32_t)rng.lo);
+                float offY = unitBits((uint32_t)(rng.lo >> 32));
                 float sx = curPixX + sampleX * args.sampleWidth + offX * args.sampleWidth;
                 float sy = curPixY + sampleY * args.sampleHeight + offY * args.sampleHeight;
                 F3 dir = p1 + dp2 * sx + dp3 * sy - origin;

@@ -8,7 +8,11 @@
 // that bench.py can time the reference's own hot loop as the CPU baseline.
 //
 // Built by oracle/Makefile into oracle/_ref/libkajo_ref*.so from the reference sources
-// where they lie under /root/reference. Never shipped, never linked by the product.
+// where they lie under /root/reference. Never linked or loaded by the product. The built
+// libraries are kept out of git history (.gitignore) but DO travel to the GPU box with the
+// snapshot, like this repo's own built .so files, so that tests and bench.py there can check
+// against, and time, the reference itself (cpu_baseline.kind "reference"); the reference's
+// SOURCES never leave /root/reference. ("What travels".)
 //
 // Per-sample stream protocol: the 128-bit cpu::Random state is
 // overwritten (16 bytes at offset 0 of the object; Random derives from the empty

@@ -16,11 +16,12 @@ cases=[('C1 256x256 S=16 depth1 1 pass',a1,256,256,16,1,1),
        ('C4 caustics 1080p 16xS32 (of 128) depth 8',caus,1920,1080,32,16,8),
        ('C5 1000 spheres/16 lights 4K 1xS32 (of 32)',stress_scene(a169,1000,16),3840,2160,32,1,8),
        ('C5 at 1080p 1xS32',stress_scene(a169,1000,16),1920,1080,32,1,8),
-       ('C5 at 1080p 8xS32',stress_scene(a169,1000,16),1920,1080,32,8,8)]
+       ('C5 at 1080p 8xS32',stress_scene(a169,1000,16),1920,1080,32,8,8),
+       ('C5 4K 32xS32 (all of its 1024 spp, 32 passes per launch)',stress_scene(a169,1000,16),3840,2160,32,32,8)]
 sel=sys.argv[1:] 
 for name,sc,W,H,S,passes,depth in cases:
     if sel and not any(s in name for s in sel): continue
-    with HipRenderer(sc,W,H,spp=S,depth_limit=depth,counters=True) as r:
+    with HipRenderer(sc,W,H,spp=S,depth_limit=depth,counters=True,passes_per_launch=passes) as r:
         r.render(passes).wait()          # warm
         c0=r.counters(); t=time.perf_counter(); r.render(passes).wait(); dt=time.perf_counter()-t; c1=r.counters()
     paths=c1['paths']-c0['paths']; ms=c1['kernelMs']-c0['kernelMs']

@@ -1,5 +1,9 @@
-for n in "" _w3 _w2 _w5 _nosched; do
-  echo "== variant libkajo_hip$n"
-  KAJO_HIP_LIB=$PWD/kajo_amd/libkajo_hip$n.so python bench.py --strict --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('strict', d['value'], d['roofline']['kernel_ms_per_launch'])"
-  KAJO_HIP_LIB=$PWD/kajo_amd/libkajo_hip$n.so python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('fast', d['value'], d['roofline']['kernel_ms_per_launch'])"
+#!/bin/bash
+# the bench (FAST and STRICT) over every build of the library found as kajo_amd/libkajo_hip*.so (KAJO_HIP_LIB)
+for lib in kajo_amd/libkajo_hip.so kajo_amd/libkajo_hip_v*.so; do
+  [ -f "$lib" ] || continue
+  echo "== $lib"
+  for mode in "" "--strict"; do
+  KAJO_HIP_LIB=$PWD/$lib python bench.py $mode --steps 8 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('  %-8s %9.1f Msamples/s  kernel %6.2f ms' % ('$mode' or 'fast', d['value'], d['roofline']['kernel_ms_per_launch']))"
+  done
 done

@@ -261,6 +261,10 @@ def main():
     r.set_stream(stream.cuda_stream)
     ptr, nbytes = r.tile_buffer()
     mine = torch.as_tensor(DevicePtr(ptr, nbytes // 4), device="cuda")
+    # the gather sends from a torch-allocated copy of the tile buffer (a device-to-device copy of 16.6 MB at N = 8, ~10 us):
+    # memory the library allocated itself is foreign to the process group's allocator, and nothing about RCCL's handling
+    # of it could be tried on the one-GPU boxes this was written on
+    send = torch.empty_like(mine) if world > 1 else None
     gathered = None
     argb = torch.empty(W * H, dtype=torch.int32, device="cuda") if rank == 0 else None
     if world > 1 and rank == 0:
@@ -275,7 +279,8 @@ def main():
         if world > 1:
             ev[0].record()
             if args.backend == "nccl":
-                gather_to_root(dist, mine, gathered, rank, world)
+                send.copy_(mine)
+                gather_to_root(dist, send, gathered, rank, world)
             else:  # rehearsal: gloo moves host tensors
                 host = torch.empty(world * mine.numel()) if rank == 0 else None
                 gather_to_root(dist, mine.cpu(), host, rank, world)

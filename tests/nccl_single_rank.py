@@ -28,7 +28,9 @@ mine = torch.as_tensor(bench.DevicePtr(ptr, nbytes // 4), device="cuda")
 gathered = torch.empty(mine.numel(), dtype=torch.float32, device="cuda")
 r.render(2).wait()
 gather_to_root(dist, mine, gathered, 0, 1)                  # world 1: returns without a collective
-dist.gather(mine, list(gathered.chunk(1)), dst=0)          # the collective itself, one-rank world
+send = torch.empty_like(mine)
+send.copy_(mine)                                            # bench.py gathers from a torch-allocated copy of the tile buffer
+dist.gather(send, list(gathered.chunk(1)), dst=0)          # the collective itself, one-rank world
 torch.cuda.current_stream().synchronize()
 t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
 dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -25,6 +25,7 @@ KAJO_FLAG_COUNTERS = 2
 KAJO_FLAG_NO_GRID = 4
 KAJO_FLAG_NO_REORDER = 8
 KAJO_FLAG_NO_SPLIT = 16
+KAJO_FLAG_COOP = 32
 
 # every symbol include/kajo_hip.h declares
 EXPORTS = [

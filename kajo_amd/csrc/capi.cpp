@@ -27,6 +27,8 @@ int kajo_render_fast_launch(const RenderArgs*, int coldInLds, unsigned grid, uns
 int kajo_render_strict_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_fast_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_strict_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
+int kajo_render_fast_coop_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
+int kajo_render_strict_coop_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_render_fast_set_lds(int coldInLds, size_t lds);
 int kajo_render_strict_set_lds(int coldInLds, size_t lds);
 int kajo_resolve_fast_launch(const void* frame, int count, float passes, void* dst, void* stream);
@@ -110,6 +112,7 @@ struct KajoHip
                                 // independently (measured +2.3 % over 4-wave groups)
     int passesDone = 0;
     size_t ldsBytes = 0, hotBytes = 0;
+    bool coop = false;   // large scenes: 512-thread workgroups with a pooled, sorted ray queue (integrator.inc.hip coopTrace)
     int stealWindow = 4; // render_args.h; 1 when a large scene needs the LDS for its grid
     int coldInLds = 1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // kernel timing
@@ -410,6 +413,21 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
             if (w == 1 || w == 2 || w == 4)
                 h->wavesPerBlock = (unsigned)w;
         }
+        // EXPERIMENT, opt-in (KAJO_FLAG_COOP or KAJO_COOP=1): scenes walked through the grid, 8 waves per workgroup pool, sort and
+        // compact their rays every trip (integrator.inc.hip coopTrace). Results are identical; it is SLOWER (C5: 1.45 against
+        // 2.04 G paths/s -- the lockstep of the 8 waves costs more than the compaction gains, and sorting by ray kind and octant
+        // does not make a wave's rays coherent enough to matter: DESIGN.md section 8). Needs the wave count of the owned tiles to
+        // be a multiple of 8 and its LDS (scene + 8 mailboxes + 25 KiB of queue) twice per CU.
+        bool coop = (p.flags & KAJO_FLAG_COOP) != 0;
+        if (const char* e = std::getenv("KAJO_COOP")) // tuning knob: 0 / 1
+            coop = std::atoi(e) != 0;
+        coop = coop && st.gridEnabled && !h->coldInLds && ((long long)h->nTilesOwned * wavesPerTile) % 8 == 0;
+        if (coop && ((h->ldsBytes + 15) & ~(size_t)15) + (size_t)8 * 64 * h->stealWindow * 16 + 1024 + 64 + 512 * 48 > 80 * 1024)
+            coop = false;
+        if (coop) {
+            h->coop = true;
+            h->wavesPerBlock = 8;
+        }
         h->gridBlocks = (unsigned)((long long)h->nTilesOwned * wavesPerTile / h->wavesPerBlock);
         if (h->gridBlocks && !(p.flags & KAJO_FLAG_NO_REORDER)) {
             CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->waveTrips), (size_t)h->gridBlocks * h->wavesPerBlock * sizeof(uint32_t)));
@@ -494,7 +512,13 @@ int kajo_hip_render(kajo_hip_t h, int passes)
     a.blockOrder = h->orderValid ? h->blockOrder : nullptr;
     a.waveTrips = (h->waveTrips && !h->orderValid) ? h->waveTrips : nullptr; // measure once, on the first launch
     // scene copy + one mailbox (64 lanes x 4 passes x float4) per wave of the workgroup
-    const size_t ldsTotal = a.mailboxOffset + (size_t)h->wavesPerBlock * 64 * h->stealWindow * 16;
+    size_t ldsTotal = a.mailboxOffset + (size_t)h->wavesPerBlock * 64 * h->stealWindow * 16;
+    if (h->coop) {
+        a.coopOffset = (uint32_t)ldsTotal;
+        if (const char* e = std::getenv("KAJO_COOP_KEY")) // experiment knob
+            a.coopKeyMode = std::atoi(e);
+        ldsTotal += 1024 + 64 + 512 * 48; // bucket counters, wave totals, 512 rays (2 x float4), 512 hits (float4)
+    }
     const int perLaunch = p.passesPerLaunch > 0 ? p.passesPerLaunch : 16;
     int left = passes;
     while (left > 0) {
@@ -532,6 +556,9 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             const size_t ldsSplit = a.mailboxOffset + (size_t)now * 64 * 16;
             le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream)
                                           : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream));
+        } else if (h->coop) {
+            le = (hipError_t)(h->strict() ? kajo_render_strict_coop_launch(&a, grid, ldsTotal, h->stream)
+                                          : kajo_render_fast_coop_launch(&a, grid, ldsTotal, h->stream));
         } else {
             le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream)
                                           : kajo_render_fast_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream));

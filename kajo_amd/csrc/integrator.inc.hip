@@ -829,6 +829,79 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     return lds;
 }
 
+// ---- cooperative traversal (large scenes, *_coop kernels) --------------------------------------------------------------
+// A walk of the grid costs a wave as much as its LONGEST ray times the FULLEST cell among its 64 lanes; the rays a wave's lanes
+// hold at one moment -- a camera ray here, a shadow ray to light 3 there, an extension ray -- share neither. Coherent rays are
+// ~5x cheaper (measured: camera rays alone walk the 1000-sphere grid at 41 G rays/s, the mix at 7.7). So the 8 waves of a
+// workgroup pool their rays every trip: each lane publishes its ray in LDS under a key (kind of ray: camera / extension /
+// shadow ray to light k; direction octant), a counting sort over the 256 keys (LDS atomics for the rank inside a bucket, a
+// wave scan for the bucket offsets) lines them up, every lane traces the ray at ITS position of the sorted queue and writes
+// the hit to the owner's slot. Lanes without a ray take no queue position: the queue is compact and the waves behind its
+// end skip the walk. A ray is traced by the same arithmetic whichever lane walks it, so every result is the one the
+// owner would have computed: STRICT stays bit-identical to the oracle.
+struct CoopLds
+{
+    uint32_t* counts;   // [256] bucket counts, then exclusive offsets
+    uint32_t* waveTot;  // [4]
+    DFloat4* rays;      // [2 * 512]: (O, owner), (d, -)
+    DFloat4* hits;      // [512]: id, t, t0
+};
+
+KDEV CoopLds coopLds(unsigned char* ldsRaw, uint32_t offset)
+{
+    CoopLds c;
+    c.counts = reinterpret_cast<uint32_t*>(ldsRaw + offset);
+    c.waveTot = c.counts + 256;
+    c.rays = reinterpret_cast<DFloat4*>(ldsRaw + offset + 1024 + 64);
+    c.hits = c.rays + 2 * 512;
+    return c;
+}
+
+// All 512 threads of the workgroup call this together, once per trip (five barriers inside, none in divergent code).
+template <bool GRID>
+KDEV Hit coopTrace(const DSceneView& sc, const LdsScene& lds, const CoopLds& co, bool hasRay, uint32_t key, F3 O, F3 d)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    key = hasRay ? key : 255u;
+    const uint32_t rank = atomicAdd(&co.counts[key], 1u); // (zeroed before the trip's first barrier)
+    __syncthreads();
+    uint32_t v = 0, incl = 0;
+    if (tid < 256u) { // waves 0..3, whole waves
+        v = co.counts[tid];
+        incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            incl += lane >= (uint32_t)o ? t : 0u;
+        }
+        if (lane == 63u)
+            co.waveTot[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < 256u) {
+        uint32_t base = 0;
+        for (uint32_t w = 0; w < wave; w++)
+            base += co.waveTot[w];
+        co.counts[tid] = base + incl - v; // exclusive offset of bucket tid
+    }
+    __syncthreads();
+    if (hasRay) {
+        const uint32_t pos = co.counts[key] + rank;
+        co.rays[2 * pos] = DFloat4{O.x, O.y, O.z, __builtin_bit_cast(float, tid)};
+        co.rays[2 * pos + 1] = DFloat4{d.x, d.y, d.z, 0.0f};
+    }
+    __syncthreads();
+    const uint32_t nRays = co.counts[255]; // bucket 255 holds the lanes without a ray: its offset is the queue length
+    if (tid < nRays) {
+        const DFloat4 ro = co.rays[2 * tid], rd = co.rays[2 * tid + 1];
+        const Hit h = trace<GRID>(sc, lds, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z));
+        co.hits[__builtin_bit_cast(uint32_t, ro.w)] = DFloat4{__builtin_bit_cast(float, h.id), h.t, h.t0, 0.0f};
+    }
+    __syncthreads();
+    const DFloat4 r = co.hits[tid];
+    return hasRay ? Hit{__builtin_bit_cast(int, r.x), r.y, r.z} : Hit{0, 0.0f, 0.0f};
+}
+
 // KAT (known-answer mode): instead of its pixel's camera paths a lane runs ONE path from a given ray
 // and RNG state and reports its radiance and the RNG state it ends in (kajo_hip_kat_shade).
 //
@@ -836,7 +909,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
 // them, so that a frame with fewer blocks than the chip has wave slots still fills it. Every pass's term radiance / S
 // goes to an LDS table [pass][pixel]; after a barrier wave 0 adds the terms to the accumulation in pass order -- the
 // float sums are those of one wave doing all the passes.
-template <bool COLD_LDS, bool KAT, bool SPLIT = false>
+template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool COOP = false>
 KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 {
     const DSceneView& sc = args.scene;
@@ -848,6 +921,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // per-wave mailbox for taken-over passes: [lane][stealWindow] float4, behind the scene copy
     const int stealWindow = args.stealWindow;
     DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.mailboxOffset) + (threadIdx.x >> 6) * (64 * stealWindow);
+
+    const CoopLds coop = coopLds(ldsRaw, COOP ? args.coopOffset : 0u);
 
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;
@@ -1073,14 +1148,32 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 mode = MODE_EXTEND;
             }
         }
-        const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
-        if (aliveMask == 0ull)
-            break;
+        if (COOP) {
+            // the workgroup's waves make their trips together: the loop ends when no lane of any wave has work left
+            if (threadIdx.x < 256u)
+                coop.counts[threadIdx.x] = 0u;
+            if (!__syncthreads_or(mode != MODE_DONE))
+                break;
+            __syncthreads(); // (the zeroed counters are in place before the first atomic, whatever the reduction does inside)
+        } else {
+            const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
+            if (aliveMask == 0ull)
+                break;
+        }
         const unsigned long long activeMask = __ballot(mode == MODE_EXTEND || mode == MODE_SHADOW); // lanes with a ray
 
         KAJO_STAMP(0); // camera-ray block
         // ---- one ray per lane through the whole scene ------------------------------------------
-        const Hit hit = trace<!COLD_LDS>(sc, lds, O, d);
+        Hit hit;
+        if (COOP) {
+            // key: what kind of ray (camera 0, extension 1, shadow ray to light k: 2 + k, capped) x direction octant
+            const uint32_t kind = mode == MODE_SHADOW ? 2u + (uint32_t)(lightK < 28 ? lightK : 28) : ((depth == 0 && !pendBsdf) ? 0u : 1u);
+            const uint32_t octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+            const uint32_t key = args.coopKeyMode == 0 ? kind * 8u + octant : (args.coopKeyMode == 1 ? 0u : (args.coopKeyMode == 2 ? kind : octant));
+            hit = coopTrace<!COLD_LDS>(sc, lds, coop, mode == MODE_EXTEND || mode == MODE_SHADOW, key, O, d);
+        } else {
+            hit = trace<!COLD_LDS>(sc, lds, O, d);
+        }
         KAJO_STAMP(1); // traversal
         if (counting) {
             ctrTraversals += __builtin_popcountll(activeMask);
@@ -1334,6 +1427,13 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERN
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBody<false, false>(args, ldsRaw);
+}
+
+// large scenes, cooperative traversal: 8 waves pool and sort their rays every trip (see coopTrace)
+extern "C" __global__ void __launch_bounds__(512, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_COOP(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<false, false, false, true>(args, ldsRaw);
 }
 
 // known-answer kernels (kajo_hip_kat_shade / kajo_hip_kat_trace): the SAME device functions, fed rays

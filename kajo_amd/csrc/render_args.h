@@ -21,6 +21,8 @@ struct RenderArgs
     int32_t tileIndex, tileCount, nTilesOwned;
     unsigned long long* counters; // [0] traversals, [1] vertices, [2] lane slots; may be null
     uint32_t mailboxOffset;       // byte offset of the pass-stealing mailboxes in dynamic LDS (16-byte aligned)
+    int32_t coopKeyMode;          // experiment knob: 0 kind x octant, 1 no sorting (compaction only), 2 kind only, 3 octant only
+    uint32_t coopOffset;          // byte offset of the cooperative-traversal area in dynamic LDS (*_coop kernels only)
     int32_t stealWindow;          // passes at the end of a launch an idle lane may take over (1..KAJO_STEAL_WINDOW_MAX): sizes the mailboxes
     // Launch-order feedback: blocks are dispatched in blockIdx order; the host sorts them by the cost the
     // previous launch measured (longest first) so that the launch does not end on its most expensive

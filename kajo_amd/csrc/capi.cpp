@@ -382,6 +382,11 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         destroy(h);
         return fail(KAJO_E_INVALID, "scene exceeds the LDS staging limit: hot records + 16 KiB of mailboxes must fit 160 KiB");
     }
+    if (const char* e = std::getenv("KAJO_STEAL_WINDOW")) { // tuning knob: passes at the end of a launch an idle lane may take over
+        const int w = std::atoi(e);
+        if (w >= 1 && w <= 16 && !st.gridEnabled)
+            h->stealWindow = w;
+    }
     // ---- tiles -----------------------------------------------------------------------------
     TileMap& m = h->map;
     m.W = width;

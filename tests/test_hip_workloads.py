@@ -3,7 +3,7 @@
   configs[1]  data/spheres.json, 1920 x 1080, 16 passes x S = 32, depth 8
   configs[2]  data/spheres.json, 3840 x 2160, 64 passes x S = 32 (the multi-GPU frame, here on one GPU and as two tile owners)
   configs[3]  the caustics scene (ideal reflector + 3 lights), 1920 x 1080, 16 of its passes, depth 8
-  configs[4]  the 1000-sphere / 16-light scene at 1920 x 1080, 2 passes (the oracle walks all 1000 spheres)
+  configs[4]  the 1000-sphere / 16-light scene at its own 3840 x 2160, 2 passes (the oracle walks all 1000 spheres)
   configs[0]  256 x 256, S = 16, depth 1, one pass -- against the reference-produced frame of tests/golden/frames2.npz
 
 The whole frame is rendered on the GPU through the C ABI; >= 8 crops of 64 x 32 pixels (glass sphere and its
@@ -177,12 +177,12 @@ def test_configs3_caustics_1080p(scenes):
     check_workload(scenes["caustics_a169"], 1920, 1080, 32, 16, 8, fast_px_budget=0.008)
 
 
-def test_configs4_stress_1000_spheres_1080p(scenes):
+def test_configs4_stress_1000_spheres_4k(scenes):
     sc = stress_scene(scenes["spheres_a169"], 1000, 16)
     # two passes: the oracle and the reference walk all 1006 primitives per ray (CPU minutes at more). 50 paths per pixel
     # among 1000 small Phong / diffuse spheres and 16 lights leave single flipped paths visible: measured 1.2-1.8 x the
     # reference's own two-build difference (as in test_hip_edge_cases.py), hence the wider slack
-    check_workload(sc, 1920, 1080, 32, 2, 8, limit=8, fast_px_budget=0.01, ppl=2, slack=2.5)
+    check_workload(sc, 3840, 2160, 32, 2, 8, limit=8, fast_px_budget=0.01, ppl=2, slack=2.5)
 
 
 def test_configs0_c1_full_size_against_the_reference(scenes, golden):

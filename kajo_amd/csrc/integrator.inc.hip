@@ -1156,9 +1156,19 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 break;
             __syncthreads(); // (the zeroed counters are in place before the first atomic, whatever the reduction does inside)
         } else {
-            const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
-            if (aliveMask == 0ull)
-                break;
+#ifdef KAJO_X_LOCKSTEP
+            // TIMING EXPERIMENT ONLY: what would it cost to keep the waves of a workgroup in step (one barrier per trip, the
+            // workgroup makes as many trips as its slowest wave) -- the precondition of any exchange of work between them?
+            if (!SPLIT && !KAT) {
+                if (!__syncthreads_or(mode != MODE_DONE))
+                    break;
+            } else
+#endif
+            {
+                const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
+                if (aliveMask == 0ull)
+                    break;
+            }
         }
         const unsigned long long activeMask = __ballot(mode == MODE_EXTEND || mode == MODE_SHADOW); // lanes with a ray
 

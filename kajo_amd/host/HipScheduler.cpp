@@ -131,7 +131,7 @@ struct Scheduler::Impl
             handles.push_back(h);
             devices.push_back(p.device);
         }
-        if (opt.gpus > 1) {
+        if (opt.gpus > 1 || opt.forceGather) {
             void* ptr = nullptr;
             check(kajo_hip_tile_buffer(handles[0], &ptr, &tileBytes), "kajo_hip_tile_buffer");
             checkHip(hipSetDevice(devices[0]), "hipSetDevice");
@@ -154,7 +154,7 @@ struct Scheduler::Impl
     // One exchange per displayed frame: every owner's tile buffer -> GPU 0
     void gatherAndCompose()
     {
-        if (opt.gpus == 1)
+        if (opt.gpus == 1 && !opt.forceGather)
             return; // single owner: the library composes from its own tiles
         const size_t count = tileBytes / sizeof(float);
         if (opt.gather == Options::Rccl) {
@@ -266,13 +266,3 @@ void Scheduler::run()
 }
 
 } // namespace hip
-
-void PassBudgetPreview::update(std::thread::id, int pass, int samples, int, int, int width, int height)
-{
-    m_pass = pass;
-    m_samples += (long long)samples * width * height;
-    if (m_verbose) {
-        double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - m_start).count();
-        std::fprintf(stderr, "pass %d  %.2f s  %.1f M nominal samples/s\n", pass, s, m_samples / s / 1e6);
-    }
-}

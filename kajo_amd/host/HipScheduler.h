@@ -41,6 +41,8 @@ struct Options
     enum Gather { Rccl, Copy } gather = Rccl; // Copy: hipMemcpyAsync instead of RCCL (also lets
                                               // several tile owners share ONE device, for tests)
     bool sameDevice = false;      // all tile owners on device 0 (needs gather = Copy)
+    bool forceGather = false;     // run the gather + compose step with ONE owner too (a one-rank communicator whose
+                                  // rank sends its tile buffer to itself): the multi-GPU call sequence on a one-GPU box
 };
 
 struct Statistics

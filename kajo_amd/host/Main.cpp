@@ -39,6 +39,7 @@ int main(int argc, char** argv)
                         "    --strict        strict numerics\n"
                         "    --gather MODE   rccl | copy (multi-GPU gather transport)\n"
                         "    --same-device   put every tile owner on GPU 0 (testing; implies --gather copy)\n"
+                        "    --force-gather  run the gather + compose step with one GPU too (testing: the RCCL call sequence at N = 1)\n"
                         "    -o FILE         PNG output (out.png)\n"
                         "    --raw FILE      also dump the float4 accumulation (W*H*4 floats)\n"
                         "    --json          print run statistics as one JSON line\n"
@@ -57,6 +58,7 @@ int main(int argc, char** argv)
         else if (a == "--strict") opt.strict = true;
         else if (a == "--gather" && more) opt.gather = args[++i] == "copy" ? hip::Options::Copy : hip::Options::Rccl;
         else if (a == "--same-device") { opt.sameDevice = true; opt.gather = hip::Options::Copy; }
+        else if (a == "--force-gather") opt.forceGather = true;
         else if (a == "-o" && more) out = args[++i];
         else if (a == "--raw" && more) rawOut = args[++i];
         else if (a == "--json") json = true;
@@ -77,7 +79,8 @@ int main(int argc, char** argv)
     }
 
     std::unique_ptr<Image> image(new Image(width, height));
-    std::unique_ptr<Preview> preview(new PassBudgetPreview(opt.passes, verbose));
+    std::unique_ptr<Preview> preview(Preview::create(image.get(), true)); // as renderer/Main.cpp:132
+    preview->setPassBudget(opt.passes, verbose);
     std::unique_ptr<Scheduler> scheduler;
     hip::Scheduler* hipScheduler = nullptr;
     opt.counters = json;

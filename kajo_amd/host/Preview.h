@@ -1,39 +1,47 @@
-// Preview.h -- the two Preview calls a backend makes (renderer/Preview.h:23-24 in the reference:
-// bool processEvents(); void update(threadId, pass, samples, xOffset, yOffset, width, height)),
-// as an interface. The reference's Preview is an SDL window; this repo's driver is headless and
-// supplies PassBudgetPreview, which "closes the window" after a number of passes -- the reference
-// itself has no stopping condition other than the window (renderer/cpu/Scheduler.cpp:74).
+// Preview.h -- headless stand-in for the reference's SDL preview window, with the reference's own
+// declarations (renderer/Preview.h:15-24): a concrete class, NON-virtual processEvents() / update(),
+// a private constructor behind `static create(Image*, bool useOpenGL)`. hip::Scheduler is compiled
+// against this header here and against the reference's renderer/Preview.h in a Kajo checkout
+// (`make -C kajo_amd/host refcheck` proves the second), so nothing in HipScheduler.{h,cpp} may use
+// anything beyond those two calls.
+//
+// The reference's window is the only stopping condition its schedulers have
+// (renderer/cpu/Scheduler.cpp:74); this one "closes" after a pass budget -- setPassBudget() and the
+// read-back accessors are additions of the headless driver (kajo_amd/host/Main.cpp), not part of the
+// reference's interface, and the backend does not call them.
 #ifndef KAJO_HOST_PREVIEW_H
 #define KAJO_HOST_PREVIEW_H
 
 #include <chrono>
+#include <memory>
 #include <thread>
+
+class Image;
 
 class Preview
 {
 public:
-    virtual ~Preview() {}
-    virtual bool processEvents() = 0;
-    virtual void update(std::thread::id threadId, int pass, int samples, int xOffset, int yOffset, int width,
-                        int height) = 0;
-};
+    ~Preview();
+    static std::unique_ptr<Preview> create(Image* image, bool useOpenGL = false);
 
-class PassBudgetPreview : public Preview
-{
-public:
-    explicit PassBudgetPreview(int passes, bool verbose = false): m_budget(passes), m_verbose(verbose) {}
-    bool processEvents() override { return m_pass < m_budget; }
-    void update(std::thread::id, int pass, int samples, int, int, int width, int height) override;
+    bool processEvents();
+    void update(std::thread::id threadId, int pass, int samples, int xOffset, int yOffset, int width, int height);
+
+    // ---- headless driver only --------------------------------------------------------------
+    void setPassBudget(int passes, bool verbose = false);
     int pass() const { return m_pass; }
-    // same accounting as Preview::update (renderer/Preview.cpp:81-82): samples * width * height per call
+    // same accounting as the reference's Preview::update (renderer/Preview.cpp:81-82): samples * width * height per call
     long long nominalSamples() const { return m_samples; }
 
 private:
+    Preview(Image* image);
+
+    Image* m_image;
     int m_budget;
     bool m_verbose;
-    int m_pass = 0;
-    long long m_samples = 0;
-    std::chrono::steady_clock::time_point m_start = std::chrono::steady_clock::now();
+    int m_pass;
+    long long m_samples;
+    std::chrono::steady_clock::time_point m_startTime;
 };
 
 #endif

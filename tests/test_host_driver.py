@@ -69,6 +69,32 @@ def test_tile_owners_and_batching_do_not_change_the_frame(tmp_path, extra):
     assert np.array_equal(acc.view(np.uint32), base.view(np.uint32))
 
 
+def test_rccl_gather_call_sequence_on_one_gpu(tmp_path):
+    # hip::Scheduler's RCCL path (ncclCommInitAll, grouped ncclSend / ncclRecv into the gather buffer, kajo_hip_compose)
+    # run with ONE owner: rank 0 sends its tile buffer to itself. Exactly the N > 1 call sequence; the frame must be the
+    # no-gather frame bit for bit. (The driver's 8-GPU run must not be this code's first execution.)
+    base, png0, _ = run(tmp_path)
+    acc, png1, stats = run(tmp_path, "--force-gather", "--gather", "rccl")
+    assert stats["gpus"] == 1
+    assert np.array_equal(acc.view(np.uint32), base.view(np.uint32))
+    assert np.array_equal(png0, png1)
+    acc, _, _ = run(tmp_path, "--force-gather", "--gather", "copy", "--batch", "1")
+    assert np.array_equal(acc.view(np.uint32), base.view(np.uint32))
+
+
+def test_driver_matches_oracle_strict(tmp_path):
+    # the C++ host path end to end (loader -> hip::Scheduler -> C ABI -> STRICT kernels) against the CPU oracle itself
+    from oraclelib import OracleLib, available
+    if not available("oracle"):
+        pytest.skip("oracle not built")
+    from kajo_amd.scene import Scene
+    acc, _, _ = run(tmp_path, "--strict")
+    z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+    sc = Scene.from_npz(z, "caustics_a169/strict_")
+    want = OracleLib("oracle").create(sc, 1).render(96, 54, S=32, passes=2)
+    assert np.array_equal(acc[..., :3].view(np.uint32), want[..., :3].view(np.uint32))
+
+
 def test_unknown_renderer_and_bad_scene(tmp_path):
     p = subprocess.run([BIN, "-r", "gl"], capture_output=True, text=True)
     assert p.returncode == 1 and "Unknown renderer" in p.stderr   # renderer/Main.cpp:139-142

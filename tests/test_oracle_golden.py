@@ -243,3 +243,16 @@ def test_full_size_workload_crops(O, golden, scenes):
                 assert np.mean((a.view(np.uint32) == rs.view(np.uint32)).all(-1)) >= (0.4 if passes > 1 else 0.85), (name, math, k)
                 s, floor = frame_stats(a / passes, rs / passes), frame_stats(rs / passes, rf / passes)
                 assert s["clamped_rmse"] <= max(1e-4, 1.25 * floor["clamped_rmse"]), (name, math, k, s, floor)
+
+
+def test_no_checker_library_switches_the_process_to_flush_to_zero():
+    # gcc links crtfastmath.o into anything LINKED with -ffast-math; its constructor sets FTZ/DAZ for the loading thread,
+    # after which the strict oracle loses its denormals (round-2 advisor finding: one pixel of the bench's parity frame).
+    # The fast-math builds are therefore compiled with the flag and linked without it (oracle/Makefile).
+    import numpy as np
+    from oraclelib import OracleLib, available
+    tiny = np.float32(1e-38)
+    for name in ("oracle", "oracle_fast", "ref", "ref_strict"):
+        if available(name):
+            OracleLib(name)
+            assert float(tiny * np.float32(0.01)) != 0.0, name

@@ -740,16 +740,15 @@ KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
 // ---- path state ---------------------------------------------------------------------------
 enum : int
 {
-    MODE_NEW = 0,    // fetch the next camera path of this lane's pixel
-    MODE_EXTEND = 1, // the traced ray continues the path: shade what it hit
-    MODE_SHADOW = 2, // the traced ray asks whether light `lightK` is visible
-    MODE_DONE = 3
+    MODE_FREE = 0,        // the lane's registers hold no path: it may start a camera path or resume a parked vertex
+    MODE_EXTEND = 1,      // the ray in (O, d) continues the path: shade what it hits
+    MODE_SHADOW_MID = 2,  // the ray asks whether a light is visible; more lights follow (the vertex stays parked)
+    MODE_SHADOW_LAST = 3, // ... the last light of the vertex: the BSDF-sampled extension ray is already waiting in d2
+    MODE_RETIRE = 4,      // the path is complete, L is its radiance
+    MODE_DONE = 5
 };
 
 } // namespace
-
-// passes at the end of a launch that an idle lane may take over: RenderArgs::stealWindow, at most 4 (64 lanes x 4 float4 = 4 KiB
-// of mailbox per wave; large scenes that need the LDS for their grid run with 1)
 
 #ifndef KAJO_WAVES_PER_SIMD
 #define KAJO_WAVES_PER_SIMD 4 // register budget: 512 / 4 = 128 VGPRs per lane
@@ -829,79 +828,30 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     return lds;
 }
 
-// ---- cooperative traversal (large scenes, *_coop kernels) --------------------------------------------------------------
-// A walk of the grid costs a wave as much as its LONGEST ray times the FULLEST cell among its 64 lanes; the rays a wave's lanes
-// hold at one moment -- a camera ray here, a shadow ray to light 3 there, an extension ray -- share neither. Coherent rays are
-// ~5x cheaper (measured: camera rays alone walk the 1000-sphere grid at 41 G rays/s, the mix at 7.7). So the 8 waves of a
-// workgroup pool their rays every trip: each lane publishes its ray in LDS under a key (kind of ray: camera / extension /
-// shadow ray to light k; direction octant), a counting sort over the 256 keys (LDS atomics for the rank inside a bucket, a
-// wave scan for the bucket offsets) lines them up, every lane traces the ray at ITS position of the sorted queue and writes
-// the hit to the owner's slot. Lanes without a ray take no queue position: the queue is compact and the waves behind its
-// end skip the walk. A ray is traced by the same arithmetic whichever lane walks it, so every result is the one the
-// owner would have computed: STRICT stays bit-identical to the oracle.
-struct CoopLds
-{
-    uint32_t* counts;   // [256] bucket counts, then exclusive offsets
-    uint32_t* waveTot;  // [4]
-    DFloat4* rays;      // [2 * 512]: (O, owner), (d, -)
-    DFloat4* hits;      // [512]: id, t, t0
-};
-
-KDEV CoopLds coopLds(unsigned char* ldsRaw, uint32_t offset)
-{
-    CoopLds c;
-    c.counts = reinterpret_cast<uint32_t*>(ldsRaw + offset);
-    c.waveTot = c.counts + 256;
-    c.rays = reinterpret_cast<DFloat4*>(ldsRaw + offset + 1024 + 64);
-    c.hits = c.rays + 2 * 512;
-    return c;
-}
-
-// All 512 threads of the workgroup call this together, once per trip (five barriers inside, none in divergent code).
-template <bool GRID>
-KDEV Hit coopTrace(const DSceneView& sc, const LdsScene& lds, const CoopLds& co, bool hasRay, uint32_t key, F3 O, F3 d)
-{
-    const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63u, wave = tid >> 6;
-    key = hasRay ? key : 255u;
-    const uint32_t rank = atomicAdd(&co.counts[key], 1u); // (zeroed before the trip's first barrier)
-    __syncthreads();
-    uint32_t v = 0, incl = 0;
-    if (tid < 256u) { // waves 0..3, whole waves
-        v = co.counts[tid];
-        incl = v;
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t t = __shfl_up(incl, o);
-            incl += lane >= (uint32_t)o ? t : 0u;
-        }
-        if (lane == 63u)
-            co.waveTot[wave] = incl;
-    }
-    __syncthreads();
-    if (tid < 256u) {
-        uint32_t base = 0;
-        for (uint32_t w = 0; w < wave; w++)
-            base += co.waveTot[w];
-        co.counts[tid] = base + incl - v; // exclusive offset of bucket tid
-    }
-    __syncthreads();
-    if (hasRay) {
-        const uint32_t pos = co.counts[key] + rank;
-        co.rays[2 * pos] = DFloat4{O.x, O.y, O.z, __builtin_bit_cast(float, tid)};
-        co.rays[2 * pos + 1] = DFloat4{d.x, d.y, d.z, 0.0f};
-    }
-    __syncthreads();
-    const uint32_t nRays = co.counts[255]; // bucket 255 holds the lanes without a ray: its offset is the queue length
-    if (tid < nRays) {
-        const DFloat4 ro = co.rays[2 * tid], rd = co.rays[2 * tid + 1];
-        const Hit h = trace<GRID>(sc, lds, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z));
-        co.hits[__builtin_bit_cast(uint32_t, ro.w)] = DFloat4{__builtin_bit_cast(float, h.id), h.t, h.t0, 0.0f};
-    }
-    __syncthreads();
-    const DFloat4 r = co.hits[tid];
-    return hasRay ? Hit{__builtin_bit_cast(int, r.x), r.y, r.z} : Hit{0, 0.0f, 0.0f};
-}
-
+// ---- the render loop ---------------------------------------------------------------------------------------------------
+// One lane = one pixel; the lane works through that pixel's n*n*passes camera paths in the reference's order, so the
+// per-pixel float sums are formed exactly as Renderer.cpp:66-71 forms them. Every trip round the loop traces ONE ray per
+// lane through the whole scene. What a lane does before and after that ray is one of two kinds of work:
+//
+//   E work   a camera ray for a new path (Renderer.cpp:51-64), and the vertex the ray finds: emission, Russian roulette,
+//            the lobe coins, refraction (Shader.cpp:113-178). Two thirds of all paths end right there.
+//   L work   for a vertex that survived: light sampling with its shadow ray and BSDF sampling (Shader.cpp:50-86,180-215).
+//
+// Round 2's kernel ran both kinds in every trip, each under its own exec mask: the L blocks -- a third of the
+// instructions -- executed with a quarter of the lanes. Here a surviving vertex is PARKED: its state (20-odd dwords) goes to
+// a per-lane FIFO in LDS (the "stash"), the lane's registers are free again and the lane starts its pixel's next camera
+// path in the very next trip. The wave runs the L blocks only in trips where enough lanes have a parked vertex
+// (RenderArgs::thrL) or are stuck without one being resumed (thrStall); every such lane then takes its oldest vertex back
+// and runs the blocks together with the others. The light sample and the BSDF sample of a vertex are drawn in ONE visit
+// (their random numbers do not depend on what the shadow ray finds: the stream order light, then BSDF, is kept): the
+// lane traces the shadow ray in that trip and the extension ray in the next, so a parked vertex needs exactly one visit of
+// the L blocks per light that has to be traced.
+//
+// Paths of one pixel therefore complete out of order. Their radiances enter the pixel's sum IN SAMPLE ORDER all the
+// same: a path carries its sequence number; one that completes while an older path of the lane is still parked leaves its
+// radiance in a small per-lane ring in LDS, and the lane adds the ring entries when the older path retires. A lane never
+// has more than ringSlots + 1 paths in flight, nor samples of more than two passes.
+//
 // KAT (known-answer mode): instead of its pixel's camera paths a lane runs ONE path from a given ray
 // and RNG state and reports its radiance and the RNG state it ends in (kajo_hip_kat_shade).
 //
@@ -909,7 +859,8 @@ KDEV Hit coopTrace(const DSceneView& sc, const LdsScene& lds, const CoopLds& co,
 // them, so that a frame with fewer blocks than the chip has wave slots still fills it. Every pass's term radiance / S
 // goes to an LDS table [pass][pixel]; after a barrier wave 0 adds the terms to the accumulation in pass order -- the
 // float sums are those of one wave doing all the passes.
-template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool COOP = false>
+#define KAJO_STASH_QUADS 6
+template <bool COLD_LDS, bool KAT, bool SPLIT = false>
 KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 {
     const DSceneView& sc = args.scene;
@@ -918,14 +869,17 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
 
-    // per-wave mailbox for taken-over passes: [lane][stealWindow] float4, behind the scene copy
+    // ---- per-wave LDS: [mailbox: 64 x stealWindow float4][ring: ringSlots x 3 x 64 float][stash: depth x 6 x 64 float4]
+    const int lane = threadIdx.x & 63;
     const int stealWindow = args.stealWindow;
-    DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.mailboxOffset) + (threadIdx.x >> 6) * (64 * stealWindow);
-
-    const CoopLds coop = coopLds(ldsRaw, COOP ? args.coopOffset : 0u);
+    unsigned char* waveLds = ldsRaw + args.perWaveOffset + (threadIdx.x >> 6) * args.perWaveBytes;
+    DFloat4* mailbox = reinterpret_cast<DFloat4*>(waveLds); // [lane][stealWindow]: passes rendered for this lane's pixel by others
+    float* ring = reinterpret_cast<float*>(waveLds + args.ringOffset) + lane;        // [slot][3][64]
+    DFloat4* stash = reinterpret_cast<DFloat4*>(waveLds + args.stashOffset) + lane;  // [entry][KAJO_STASH_QUADS][64]
+    const int stashDepth = args.stashDepth;           // power of two
+    const uint32_t ringMask = (uint32_t)args.ringSlots - 1u; // ringSlots: power of two
 
     // ---- which pixel is mine ----------------------------------------------------------------
-    const int lane = threadIdx.x & 63;
     const uint32_t logicalBlock = (!KAT && args.blockOrder) ? args.blockOrder[blockIdx.x] : blockIdx.x;
     const int splitWave = SPLIT ? (int)(threadIdx.x >> 6) : 0;
     const int splitCount = SPLIT ? (int)(blockDim.x >> 6) : 1;
@@ -955,7 +909,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // x * pixelWidth and (H - y) * pixelHeight of Renderer.cpp:56-57 are constants of the pixel
     const float pixX = px * args.pixelWidth;
     const float pixY = (args.H - py) * args.pixelHeight;
-    // The pixel whose pass the lane is rendering right now: its own, or -- near the end of the wave's
+    // The pixel whose pass the lane is ISSUING camera paths for: its own, or -- near the end of the wave's
     // life -- one taken over from a lane that still has whole passes left (see "pass stealing" below).
     uint32_t curKeyA = keyA;
     float curPixX = pixX, curPixY = pixY;
@@ -971,11 +925,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     }
     bool katStarted = false;
 
-    // ---- per-lane path state ----------------------------------------------------------------
-    int mode = inImage ? MODE_NEW : MODE_DONE;
+    // ---- the lane's passes --------------------------------------------------------------------
+    int mode = inImage ? MODE_FREE : MODE_DONE;
     const int passesMine = SPLIT ? args.nPasses / splitCount : args.nPasses; // the host launches SPLIT only when this divides
     const int firstMine = args.firstPass + splitWave * passesMine;
-    int pass = firstMine;                       // pass being rendered (own or taken over)
     const int lastPass = firstMine + passesMine; // exclusive
     // Pass stealing. A pass of a pixel is a self-contained piece of work (its n*n paths have their own
     // streams, its sum enters the pixel's total as one term), so a lane that has finished its own pixel
@@ -983,26 +936,44 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // leaves radiance / S in a mailbox in LDS; the owner adds the mailbox terms after its own passes, in
     // pass order -- the float sums are formed exactly as without stealing. Only the last `stealWindow`
     // passes of a launch can be given away (that is all the imbalance there is, and bounds the mailbox).
-    int ownPass = firstMine; // next pass of the lane's own pixel
-    int myEnd = inImage ? lastPass : firstMine; // own passes [ownPass, myEnd); shrinks when one is taken over
-    int stolenFrom = -1;          // lane whose pass is being rendered, or -1
     const int stealBase = lastPass - stealWindow > firstMine ? lastPass - stealWindow : firstMine;
-    int sampleX = 0, sampleY = 0;
-    F3 radiance = f3(0.0f, 0.0f, 0.0f); // sum over the pixel's samples of this pass
+    // ISSUE side: the pass whose camera paths are being started
+    int pass = firstMine;            // (own or taken over)
+    int ownPass = firstMine;         // next pass of the lane's own pixel that has not been opened
+    int myEnd = inImage ? lastPass : firstMine; // own passes [.., myEnd); shrinks when one is taken over
+    int stolenFrom = -1;             // lane whose pass is being issued, or -1
+    int sampleX = 0, sampleY = n;    // sampleY == n: every sample of the issue pass has been started (or no pass is open yet)
+    bool exhausted = false;          // no pass left to open, neither own nor anyone else's
+    // RETIRE side: the pass whose samples are entering `radiance`. It is the issue pass itself (aheadBy == 0) or the one
+    // before it (aheadBy == 1, described by aPass / aStolen); a lane never opens a pass while it is one ahead.
+    F3 radiance = f3(0.0f, 0.0f, 0.0f); // sum over the retired samples of the retiring pass, in sample order
+    int aLeft = 0;                   // samples of the retiring pass not yet retired (0: nothing open on the retire side)
+    int aPass = 0, aStolen = -1, aheadBy = 0;
+    uint32_t issued = 0, retired = 0; // sequence numbers of the lane's paths (mod 2^32; their difference is what matters)
+    uint32_t doneMask = 0;            // ring slots that hold the radiance of a completed, not yet retired path
+    int stashHead = 0, stashCount = 0; // FIFO of parked vertices: entries (stashHead + i) & (stashDepth - 1), i < stashCount
+
+    // ---- the path in the lane's registers ------------------------------------------------------
     Rng rng{0, 0};
     F3 O = origin, d = f3(0.0f, 0.0f, 1.0f);
     F3 L = f3(0.0f, 0.0f, 0.0f), T = f3(1.0f, 1.0f, 1.0f);
     int depth = 0;
     bool collectEmission = true;
-    // vertex being shaded
-    F3 vP = origin, vN = d, vR = d, vE = L, vLd = L, vColor = L;
-    int vId = 0, vKind = 0, lightK = 0;
-    float vExp = 0.0f, vS = 0.0f;
-    F3 pendContrib = L; // light sample's contribution if its shadow ray reaches the light
+    uint32_t seq = 0;                // sequence number of the path
+    // the vertex the path left last: position, object, path-weight scale (MIS correction of the extension ray, Shader.cpp:203-212)
+    F3 vP = origin;
+    int vId = 0;
+    float vS = 0.0f;
     // extension ray sampled from the BSDF: weight pieces that wait for the light pdf of the hit
     bool pendBsdf = false;
     F3 pendF = L, pendT = L;
     float pendCos = 0.0f, pendP = 0.0f;
+    // shadow ray in flight
+    F3 pendContrib = L; // the light sample's contribution if the shadow ray reaches the light
+    int lightObj = 0;   // object id of that light
+    // MODE_SHADOW_LAST: what the vertex adds once the shadow ray is back, and the extension ray that follows
+    F3 vE = L, vLd = L, d2 = L;
+    bool extOk = false;
 
     unsigned long long ctrTraversals = 0, ctrVertices = 0, ctrSlots = 0;
     const bool counting = args.counters != nullptr;
@@ -1042,15 +1013,27 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #if !KAJO_STRICT
     const float invS = krcp(args.S);
 #endif
+    const int nn = n * n;
+    // the last light a vertex with object id `id` samples (a light does not sample itself, Shader.cpp:60-61): -1 if none
+    const int lastLightAll = sc.nLights - 1;
+    const int lastLightObj = sc.nLights > 0 ? np + 1 + lds.light[sc.nLights - 1] : -1;
+
     uint32_t trips = 0;
     for (;;) {
         trips++;
-        KAJO_STAMP(4); // tail of the previous trip (path bookkeeping, loop back-edge)
-        // ---- MODE_NEW: camera ray of the next sample (Renderer.cpp:51-64) ---------------------
-        KAJO_PROF(0, mode == MODE_NEW);
-        if (KAT && mode == MODE_NEW) {
+        KAJO_STAMP(4); // tail of the previous trip (retirement, loop back-edge)
+
+        // ---- do the L blocks run in this trip? (wave-uniform) --------------------------------------
+        const bool windowOpen = issued - retired <= ringMask + 1u; // ringSlots paths may wait in the ring behind the oldest
+        const bool parked = mode == MODE_FREE && stashCount > 0;
+        const bool stuck = parked && (stashCount >= stashDepth || !windowOpen || exhausted || (sampleY == n && aheadBy != 0));
+        bool runL = __builtin_popcountll(__ballot(parked)) >= args.thrL || __builtin_popcountll(__ballot(stuck)) >= args.thrStall;
+
+        // ---- E work, before the ray: the camera ray of the pixel's next sample (Renderer.cpp:51-64) ---
+        if (KAT && mode == MODE_FREE && !(runL && parked)) {
             if (katStarted) {
-                mode = MODE_DONE;
+                if (stashCount == 0)
+                    mode = MODE_DONE;
             } else {
                 katStarted = true;
                 O = ld3(args.katRays + 6 * slot);
@@ -1062,44 +1045,30 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 depth = 0;
                 collectEmission = true;
                 pendBsdf = false;
+                seq = issued++;
                 mode = MODE_EXTEND;
             }
         }
-        if (!KAT && mode == MODE_NEW) {
-            if (sampleY == n) { // pass complete: Renderer.cpp:70-71
-#if KAJO_STRICT
-                const F3 term = f3(radiance.x / args.S, radiance.y / args.S, radiance.z / args.S);
-#else
-                const F3 term = radiance * invS;
-#endif
-                if (SPLIT) { // own or taken over: the term goes to the table, under its pass and pixel
-                    termTable[(pass - args.firstPass) * 64 + (stolenFrom >= 0 ? stolenFrom : lane)] = DFloat4{term.x, term.y, term.z, 0.0f};
-                    if (stolenFrom >= 0)
-                        stolenFrom = -1;
-                    else
-                        ownPass++;
-                } else if (stolenFrom >= 0) {
-                    mailbox[stolenFrom * stealWindow + (pass - stealBase)] = DFloat4{term.x, term.y, term.z, 0.0f};
-                    stolenFrom = -1;
-                } else {
-                    total = total + term;
-                    ownPass++;
-                }
-                radiance = f3(0.0f, 0.0f, 0.0f);
-                sampleY = 0;
-                pass = ownPass;
-                curKeyA = keyA;
-                curPixX = pixX;
-                curPixY = pixY;
+        KAJO_PROF(0, !KAT && mode == MODE_FREE && !(runL && parked));
+        if (!KAT && mode == MODE_FREE && !(runL && parked)) {
+            // (a) the issue pass is used up: open the next one -- an own pass, or one taken over
+            bool wantPass = sampleY == n && aheadBy == 0 && !exhausted;
+            bool opened = false;
+            int newPass = 0, newStolen = -1;
+            uint32_t newKey = keyA;
+            float newX = pixX, newY = pixY;
+            if (wantPass && ownPass < myEnd) {
+                newPass = ownPass++;
+                opened = true;
             }
-            // out of own passes: take one over, or retire when nobody has one to give
-            unsigned long long idleMask = __ballot(stolenFrom < 0 && ownPass >= myEnd);
+            // out of own passes: take one over, or give up when nobody has one to give
+            unsigned long long idleMask = __ballot(wantPass && !opened);
             while (idleMask) { // wave-uniform; only in the last stretch of the wave's life
-                const int give = myEnd - 1; // the pass this lane could give away
-                const unsigned long long giverMask = __ballot(mode != MODE_DONE && stolenFrom < 0 && give > ownPass && give >= stealBase);
+                const int give = myEnd - 1; // the pass this lane could give away: its last, if not opened yet
+                const unsigned long long giverMask = __ballot(!exhausted && give >= ownPass && give >= stealBase);
                 if (giverMask == 0ull) {
-                    if (stolenFrom < 0 && ownPass >= myEnd)
-                        mode = MODE_DONE;
+                    if (wantPass && !opened)
+                        exhausted = true;
                     break;
                 }
                 // lowest idle lane takes the last pass of the lowest giver
@@ -1111,15 +1080,33 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 if (lane == giver)
                     myEnd = takenPass;
                 if (lane == thief) {
-                    stolenFrom = giver;
-                    pass = takenPass;
-                    curKeyA = gKey;
-                    curPixX = gX;
-                    curPixY = gY;
+                    opened = true;
+                    newStolen = giver;
+                    newPass = takenPass;
+                    newKey = gKey;
+                    newX = gX;
+                    newY = gY;
                 }
                 idleMask &= idleMask - 1; // next idle lane
             }
-            if (mode == MODE_NEW && (stolenFrom >= 0 || ownPass < myEnd)) {
+            if (opened) {
+                if (aLeft > 0) { // samples of the pass just issued are still in flight: it stays the retiring pass
+                    aPass = pass;
+                    aStolen = stolenFrom;
+                    aheadBy = 1;
+                } else {
+                    aLeft = nn;
+                }
+                pass = newPass;
+                stolenFrom = newStolen;
+                curKeyA = newKey;
+                curPixX = newX;
+                curPixY = newY;
+                sampleX = 0;
+                sampleY = 0;
+            }
+            // (b) one camera path, if the lane may start one: a slot of the stash must be free for the vertex it may park
+            if (sampleY < n && stashCount < stashDepth && windowOpen) {
                 uint32_t a = curKeyA, c = keyC ^ ((uint32_t)pass >> 16), dd = keyD;
                 uint32_t b = ((uint32_t)(sampleY * n + sampleX) | ((uint32_t)pass << 16)) ^ 0x3320646eu;
                 KAJO_QUARTER_ROUND(a, b, c, dd);
@@ -1140,162 +1127,51 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 depth = 0;
                 collectEmission = true;
                 pendBsdf = false;
+                seq = issued++;
                 sampleX++;
                 if (sampleX == n) {
                     sampleX = 0;
                     sampleY++;
                 }
                 mode = MODE_EXTEND;
+            } else if (exhausted && issued == retired) {
+                mode = MODE_DONE;
             }
         }
-        if (COOP) {
-            // the workgroup's waves make their trips together: the loop ends when no lane of any wave has work left
-            if (threadIdx.x < 256u)
-                coop.counts[threadIdx.x] = 0u;
-            if (!__syncthreads_or(mode != MODE_DONE))
-                break;
-            __syncthreads(); // (the zeroed counters are in place before the first atomic, whatever the reduction does inside)
-        } else {
-#ifdef KAJO_X_LOCKSTEP
-            // TIMING EXPERIMENT ONLY: what would it cost to keep the waves of a workgroup in step (one barrier per trip, the
-            // workgroup makes as many trips as its slowest wave) -- the precondition of any exchange of work between them?
-            if (!SPLIT && !KAT) {
-                if (!__syncthreads_or(mode != MODE_DONE))
-                    break;
-            } else
-#endif
-            {
-                const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
-                if (aliveMask == 0ull)
-                    break;
-            }
-        }
-        const unsigned long long activeMask = __ballot(mode == MODE_EXTEND || mode == MODE_SHADOW); // lanes with a ray
-
         KAJO_STAMP(0); // camera-ray block
-        // ---- one ray per lane through the whole scene ------------------------------------------
-        Hit hit;
-        if (COOP) {
-            // key: what kind of ray (camera 0, extension 1, shadow ray to light k: 2 + k, capped) x direction octant
-            const uint32_t kind = mode == MODE_SHADOW ? 2u + (uint32_t)(lightK < 28 ? lightK : 28) : ((depth == 0 && !pendBsdf) ? 0u : 1u);
-            const uint32_t octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
-            const uint32_t key = args.coopKeyMode == 0 ? kind * 8u + octant : (args.coopKeyMode == 1 ? 0u : (args.coopKeyMode == 2 ? kind : octant));
-            hit = coopTrace<!COLD_LDS>(sc, lds, coop, mode == MODE_EXTEND || mode == MODE_SHADOW, key, O, d);
-        } else {
-            hit = trace<!COLD_LDS>(sc, lds, O, d);
-        }
-        KAJO_STAMP(1); // traversal
-        if (counting) {
-            ctrTraversals += __builtin_popcountll(activeMask);
-            ctrSlots += 64;
-        }
 
-        bool sampleNext = false; // continue with the light loop / BSDF sampling of vertex v*
-        bool pathDone = false;
-        KAJO_PROF(1, mode == MODE_EXTEND && pendBsdf && hit.id > np);
-        KAJO_PROF(2, mode == MODE_EXTEND && hit.id != 0);
-        KAJO_PROF(6, mode == MODE_SHADOW);
+        // ---- L work, before the ray: resume a parked vertex (Shader.cpp:50-86,180-200) --------------------
+        // When no lane of the wave has a ray to trace, the parked vertices are all there is to do.
+        if (!runL && __ballot(mode == MODE_EXTEND || mode == MODE_SHADOW_MID || mode == MODE_SHADOW_LAST) == 0ull)
+            runL = true;
+        KAJO_PROF(1, runL && mode == MODE_FREE && stashCount > 0);
+        if (runL && mode == MODE_FREE && stashCount > 0) {
+            DFloat4* e = stash + (size_t)stashHead * (KAJO_STASH_QUADS * 64);
+            const DFloat4 q0 = e[0], q1 = e[64], q2 = e[128], q3 = e[192], q4 = e[256], q5 = e[320];
+            rng.lo = (uint64_t)__builtin_bit_cast(uint32_t, q0.x) | ((uint64_t)__builtin_bit_cast(uint32_t, q0.y) << 32);
+            rng.hi = (uint64_t)__builtin_bit_cast(uint32_t, q0.z) | ((uint64_t)__builtin_bit_cast(uint32_t, q0.w) << 32);
+            L = f3(q1.x, q1.y, q1.z);
+            T = f3(q2.x, q2.y, q2.z);
+            vP = f3(q3.x, q3.y, q3.z);
+            const F3 vN = f3(q4.x, q4.y, q4.z);
+            const F3 view = f3(q5.x, q5.y, q5.z);
+            vLd = f3(q3.w, q4.w, q5.w);
+            const uint32_t pk0 = __builtin_bit_cast(uint32_t, q1.w), pk1 = __builtin_bit_cast(uint32_t, q2.w);
+            vId = (int)(pk0 & 0x3ffffu);
+            depth = (int)((pk0 >> 18) & 0x3ffu);
+            collectEmission = ((pk0 >> 28) & 1u) != 0u;
+            const int vKind = (int)((pk0 >> 29) & 3u);
+            int lightK = (int)(pk1 & 0xffffu);
+            seq = (pk1 >> 16) & 0xffu; // sequence numbers are compared in their low 8 bits: a lane has a handful of paths in flight
+            const DMaterial& m = lds.material[vId - 1];
+            vE = collectEmission ? ld3(m.emission) : f3(0.0f, 0.0f, 0.0f); // Shader.cpp:121
+            const F3 vColor = vKind == 0 ? ld3(m.diffuse) : ld3(m.specular);
+            const float vExp = m.exponent;
+            vS = vKind == 0 ? m.sDiffuse : m.sSpecular; // 1/pc * 1/pt * 1/pd, Shader.cpp:160-177 (formed on the host in this order)
+            const F3 vR = reflect(view, vN);
+            const int lastLight = vId == lastLightObj ? lastLightAll - 1 : lastLightAll;
 
-        if (mode == MODE_EXTEND) {
-            // Weight of the BSDF-sampled segment that just ended (Shader.cpp:203-212). The throughput was
-            // advanced with a zero light pdf when the direction was sampled (0 + p == p exactly); only a ray
-            // that lands on a light other than the vertex it left needs the MIS denominator pL + p.
-            if (pendBsdf) {
-                // (A light that is a pure emitter -- no diffuse, specular or transparent colour, pRR == 0 -- ends every path
-                // that reaches it, and a path that arrives over a BSDF-sampled segment collects no emission there
-                // (Shader.cpp:121,212): its throughput is never used again, so the MIS correction is skipped. STRICT
-                // keeps it when the throughput is not finite: NaN * 0 must stay NaN.)
-                const DMaterial& hm = lds.material[hit.id > 0 ? hit.id - 1 : 0];
-#if KAJO_STRICT
-                const bool weightMatters = hm.pRR != 0.0f || !(__builtin_fabsf(T.x) < __builtin_inff() && __builtin_fabsf(T.y) < __builtin_inff() && __builtin_fabsf(T.z) < __builtin_inff());
-#else
-                const bool weightMatters = hm.pRR != 0.0f;
-#endif
-                if (hit.id > np && hit.id != vId && hm.isLight && weightMatters) {
-                    const DSphereCold& lc = lds.sphereCold[hit.id - 1 - np];
-#if KAJO_STRICT
-                    const float pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));
-#else
-                    const float pL = lightPdf(lc, vP);
-#endif
-                    const F3 wb = (krcp(pL + pendP) * pendF) * pendCos;
-                    T = pendT * (vS * wb);
-                }
-                collectEmission = false; // SampleNonEmissiveObjects
-                pendBsdf = false;
-            }
-            if (hit.id == 0) { // Shader.cpp:116-117
-                L = L + T * background;
-                pathDone = true;
-            } else {
-                if (counting)
-                    ctrVertices += 1;
-                const DMaterial& m = lds.material[hit.id - 1];
-                const F3 view = d;
-                vP = O + d * hit.t; // Raytracer.cpp:134-135
-                vN = hitNormal(sc, lds, hit, O, d);
-                vId = hit.id;
-                vE = collectEmission ? ld3(m.emission) : f3(0.0f, 0.0f, 0.0f); // Shader.cpp:121
-                float pc;
-                const bool cont = flipCoin(rng, m.pRR, pc); // Shader.cpp:124-125
-                if (!cont || depth >= args.depthLimit) {
-#if KAJO_STRICT
-                    L = L + T * (krcp(pc) * vE); // Shader.cpp:126-127
-#else
-                    L = L + T * ((cont ? m.sDepth : m.sStop) * vE);
-#endif
-                    pathDone = true;
-                } else {
-                    float pt;
-                    const bool transparent = flipCoin(rng, m.pT, pt); // Shader.cpp:130-134
-                    KAJO_PROF(3, transparent);
-                    KAJO_PROF(4, !transparent);
-                    if (transparent) { // Shader.cpp:137-151; the BSDF colour is the SPECULAR colour
-                        F3 nd = transmissionDirection(view, vN, m.ior);
-                        float cosA = __builtin_fabsf(dot(nd, vN));
-                        F3 spec = ld3(m.specular);
-                        F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
-#if KAJO_STRICT
-                        F3 w = (kdiv(krcp(pc) * 1.0f, pt) * f) * __builtin_fabsf(dot(vN, nd));
-#else
-                        F3 w = (m.sTransparent * f) * __builtin_fabsf(dot(vN, nd));
-#endif
-                        L = L + T * (w * vE);
-                        T = T * w;
-                        O = vP + nd * kEps;
-                        d = nd;
-                        depth++;
-                        // mode stays MODE_EXTEND, the light sampling scheme is inherited
-                    } else {
-                        float pd;
-                        const bool diffuse = flipCoin(rng, m.pD, pd); // Shader.cpp:153-154
-                        vKind = diffuse ? 0 : (m.exponent != 0.0f ? 1 : 2);
-                        vColor = diffuse ? ld3(m.diffuse) : ld3(m.specular);
-                        vExp = m.exponent;
-#if KAJO_STRICT
-                        vS = kdiv(kdiv(krcp(pc) * 1.0f, pt) * 1.0f, pd); // 1/pc * 1/pt * 1/pd
-#else
-                        vS = diffuse ? m.sDiffuse : m.sSpecular;
-#endif
-                        vR = reflect(view, vN);
-                        vLd = f3(0.0f, 0.0f, 0.0f);
-                        lightK = 0;
-                        sampleNext = true;
-                    }
-                }
-            }
-        } else if (mode == MODE_SHADOW) {
-            // Shader.cpp:72-73: the sample counts iff the closest hit of the shadow ray IS the light
-            if (hit.id == np + 1 + lds.light[lightK])
-                vLd = vLd + pendContrib;
-            lightK++;
-            sampleNext = true;
-        }
-
-        KAJO_STAMP(2); // vertex / shadow-result block
-        KAJO_PROF(5, sampleNext);
-        if (sampleNext) {
-            // ---- sampleLights (Shader.cpp:50-86), one light per trip ------------------------------
+            // ---- sampleLights (Shader.cpp:50-86), one light per visit ------------------------------
             bool shadowRay = false;
             while (lightK < sc.nLights) {
                 const int si = lds.light[lightK];
@@ -1326,13 +1202,23 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
                 const F3 Le = ld3(lds.material[np + si].emission);
                 pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
-                mode = MODE_SHADOW;
+                lightObj = np + 1 + si;
                 shadowRay = true;
                 break;
             }
-            KAJO_PROF(7, !shadowRay);
-            if (!shadowRay) {
-                // ---- BSDF sampling (Shader.cpp:191-200) ------------------------------------------
+            KAJO_PROF(2, shadowRay);
+            if (shadowRay && lightK < lastLight) {
+                // more lights follow: the vertex stays parked at the head of the FIFO with the stream and the light index
+                // moved on; the shadow ray's answer is added to its vLd after the trace
+                e[0] = DFloat4{__builtin_bit_cast(float, (uint32_t)rng.lo), __builtin_bit_cast(float, (uint32_t)(rng.lo >> 32)),
+                               __builtin_bit_cast(float, (uint32_t)rng.hi), __builtin_bit_cast(float, (uint32_t)(rng.hi >> 32))};
+                reinterpret_cast<uint32_t*>(e + 128)[3] = (pk1 & 0xffff0000u) | (uint32_t)(lightK + 1);
+                mode = MODE_SHADOW_MID;
+            } else {
+                // ---- BSDF sampling (Shader.cpp:191-200): the vertex leaves the stash ------------------
+                KAJO_PROF(3, true);
+                stashHead = (stashHead + 1) & (stashDepth - 1);
+                stashCount--;
                 F3 tg = f3(0.0f, 0.0f, 0.0f), bn = tg;
                 if (vKind == 0) {
                     if (vId <= np) {
@@ -1345,33 +1231,194 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
                 float p;
                 F3 fd;
-                d = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
-                L = L + T * (vS * (vE + vLd));
-                // The next segment's state is written unconditionally: a path that ends here (p == 0) re-initialises
-                // all of it when its lane starts the next camera path, and unconditional writes need no copies.
+                d2 = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
                 pendF = fd;
-                pendCos = kmax0(dot(vN, d));
+                pendCos = kmax0(dot(vN, d2));
                 pendP = p;
                 pendBsdf = true;
                 pendT = T;
                 T = T * (vS * ((krcp(0.0f + p) * pendF) * pendCos));
-                O = vP + d * kEps;
                 depth++;
-                if (p == 0.0f)
-                    pathDone = true;
-                else
-                    mode = MODE_EXTEND;
+                extOk = p != 0.0f;
+                if (shadowRay) {
+                    mode = MODE_SHADOW_LAST; // (O, d) is the shadow ray; L waits for its answer
+                } else {
+                    L = L + pendT * (vS * (vE + vLd));
+                    O = vP + d2 * kEps;
+                    d = d2;
+                    mode = extOk ? MODE_EXTEND : MODE_RETIRE;
+                }
             }
         }
+        KAJO_STAMP(1); // light + BSDF sampling block
 
-        KAJO_STAMP(3); // light loop + BSDF sampling block
-        if (pathDone) {
-            radiance = radiance + L; // Renderer.cpp:66
-            mode = MODE_NEW;
+        {
+            const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
+            if (aliveMask == 0ull)
+                break;
+        }
+        const bool hasRay = mode == MODE_EXTEND || mode == MODE_SHADOW_MID || mode == MODE_SHADOW_LAST;
+
+        // ---- one ray per lane through the whole scene ------------------------------------------
+        const Hit hit = trace<!COLD_LDS>(sc, lds, O, d);
+        KAJO_STAMP(2); // traversal
+        if (counting) {
+            ctrTraversals += __builtin_popcountll(__ballot(hasRay));
+            ctrSlots += 64;
+        }
+
+        // ---- L work, after the ray: the shadow ray's answer -------------------------------------------
+        KAJO_PROF(7, mode == MODE_SHADOW_MID || mode == MODE_SHADOW_LAST);
+        if (mode == MODE_SHADOW_MID) {
+            // Shader.cpp:72-73: the sample counts iff the closest hit of the shadow ray IS the light
+            if (hit.id == lightObj) {
+                float* e = reinterpret_cast<float*>(stash + (size_t)stashHead * (KAJO_STASH_QUADS * 64));
+                e[192 * 4 + 3] = e[192 * 4 + 3] + pendContrib.x;
+                e[256 * 4 + 3] = e[256 * 4 + 3] + pendContrib.y;
+                e[320 * 4 + 3] = e[320 * 4 + 3] + pendContrib.z;
+            }
+            mode = MODE_FREE;
+        } else if (mode == MODE_SHADOW_LAST) {
+            if (hit.id == lightObj)
+                vLd = vLd + pendContrib;
+            L = L + pendT * (vS * (vE + vLd));
+            O = vP + d2 * kEps;
+            d = d2;
+            mode = extOk ? MODE_EXTEND : MODE_RETIRE;
+        } else if (mode == MODE_EXTEND) {
+            // ---- E work, after the ray: the vertex (Shader.cpp:113-178) -----------------------------------
+            // Weight of the BSDF-sampled segment that just ended (Shader.cpp:203-212). The throughput was
+            // advanced with a zero light pdf when the direction was sampled (0 + p == p exactly); only a ray
+            // that lands on a light other than the vertex it left needs the MIS denominator pL + p.
+            if (pendBsdf) {
+                // (A light that is a pure emitter -- no diffuse, specular or transparent colour, pRR == 0 -- ends every path
+                // that reaches it, and a path that arrives over a BSDF-sampled segment collects no emission there
+                // (Shader.cpp:121,212): its throughput is never used again, so the MIS correction is skipped. STRICT
+                // keeps it when the throughput is not finite: NaN * 0 must stay NaN.)
+                const DMaterial& hm = lds.material[hit.id > 0 ? hit.id - 1 : 0];
+#if KAJO_STRICT
+                const bool weightMatters = hm.pRR != 0.0f || !(__builtin_fabsf(T.x) < __builtin_inff() && __builtin_fabsf(T.y) < __builtin_inff() && __builtin_fabsf(T.z) < __builtin_inff());
+#else
+                const bool weightMatters = hm.pRR != 0.0f;
+#endif
+                if (hit.id > np && hit.id != vId && hm.isLight && weightMatters) {
+                    const DSphereCold& lc = lds.sphereCold[hit.id - 1 - np];
+#if KAJO_STRICT
+                    const float pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));
+#else
+                    const float pL = lightPdf(lc, vP);
+#endif
+                    const F3 wb = (krcp(pL + pendP) * pendF) * pendCos;
+                    T = pendT * (vS * wb);
+                }
+                collectEmission = false; // SampleNonEmissiveObjects
+                pendBsdf = false;
+            }
+            KAJO_PROF(4, hit.id != 0);
+            if (hit.id == 0) { // Shader.cpp:116-117
+                L = L + T * background;
+                mode = MODE_RETIRE;
+            } else {
+                if (counting)
+                    ctrVertices += 1;
+                const DMaterial& m = lds.material[hit.id - 1];
+                const F3 view = d;
+                vP = O + d * hit.t; // Raytracer.cpp:134-135
+                const F3 vN = hitNormal(sc, lds, hit, O, d);
+                vId = hit.id;
+                const F3 em = collectEmission ? ld3(m.emission) : f3(0.0f, 0.0f, 0.0f); // Shader.cpp:121
+                float pc;
+                const bool cont = flipCoin(rng, m.pRR, pc); // Shader.cpp:124-125
+                if (!cont || depth >= args.depthLimit) {
+                    // Shader.cpp:126-127: 1 / pc with pc = pRR (depth limit) or 1 - pRR (the coin said stop), formed on the host
+                    L = L + T * ((cont ? m.sDepth : m.sStop) * em);
+                    mode = MODE_RETIRE;
+                } else {
+                    float pt;
+                    const bool transparent = flipCoin(rng, m.pT, pt); // Shader.cpp:130-134
+                    KAJO_PROF(5, transparent);
+                    if (transparent) { // Shader.cpp:137-151; the BSDF colour is the SPECULAR colour
+                        F3 nd = transmissionDirection(view, vN, m.ior);
+                        float cosA = __builtin_fabsf(dot(nd, vN));
+                        F3 spec = ld3(m.specular);
+                        F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
+                        F3 w = (m.sTransparent * f) * __builtin_fabsf(dot(vN, nd)); // sTransparent = 1/pc * 1/pt
+                        L = L + T * (w * em);
+                        T = T * w;
+                        O = vP + nd * kEps;
+                        d = nd;
+                        depth++;
+                        // mode stays MODE_EXTEND, the light sampling scheme is inherited
+                    } else {
+                        // The vertex survives and wants its lights and a BSDF sample: park it (the lane had a free slot
+                        // when it traced this ray) and free the registers for the pixel's next camera path.
+                        float pd;
+                        const bool diffuse = flipCoin(rng, m.pD, pd); // Shader.cpp:153-154
+                        const uint32_t vKind = diffuse ? 0u : (m.exponent != 0.0f ? 1u : 2u);
+                        KAJO_PROF(6, true);
+                        DFloat4* e = stash + (size_t)((stashHead + stashCount) & (stashDepth - 1)) * (KAJO_STASH_QUADS * 64);
+                        const uint32_t pk0 = (uint32_t)vId | ((uint32_t)depth << 18) | (collectEmission ? 1u << 28 : 0u) | (vKind << 29);
+                        const uint32_t pk1 = (seq & 0xffu) << 16; // light index 0
+                        e[0] = DFloat4{__builtin_bit_cast(float, (uint32_t)rng.lo), __builtin_bit_cast(float, (uint32_t)(rng.lo >> 32)),
+                                       __builtin_bit_cast(float, (uint32_t)rng.hi), __builtin_bit_cast(float, (uint32_t)(rng.hi >> 32))};
+                        e[64] = DFloat4{L.x, L.y, L.z, __builtin_bit_cast(float, pk0)};
+                        e[128] = DFloat4{T.x, T.y, T.z, __builtin_bit_cast(float, pk1)};
+                        e[192] = DFloat4{vP.x, vP.y, vP.z, 0.0f};
+                        e[256] = DFloat4{vN.x, vN.y, vN.z, 0.0f};
+                        e[320] = DFloat4{view.x, view.y, view.z, 0.0f};
+                        stashCount++;
+                        mode = MODE_FREE;
+                    }
+                }
+            }
+        }
+        KAJO_STAMP(3); // vertex / shadow-result block
+
+        // ---- a completed path: its radiance joins the pixel's sum in sample order (Renderer.cpp:66) ----------
+        if (mode == MODE_RETIRE) {
+            mode = MODE_FREE;
             if (KAT) {
                 reinterpret_cast<float4*>(args.katRgb)[slot] = make_float4(L.x, L.y, L.z, 0.0f);
                 args.katFinal[2 * slot] = rng.lo;
                 args.katFinal[2 * slot + 1] = rng.hi;
+                retired++;
+            } else if (((seq ^ retired) & 0xffu) != 0u) {
+                // an older path of this lane is still parked: wait in the ring
+                const uint32_t s = seq & ringMask;
+                ring[(s * 3 + 0) * 64] = L.x;
+                ring[(s * 3 + 1) * 64] = L.y;
+                ring[(s * 3 + 2) * 64] = L.z;
+                doneMask |= 1u << s;
+            } else {
+                F3 add = L;
+                for (;;) {
+                    radiance = radiance + add;
+                    retired++;
+                    if (--aLeft == 0) { // the retiring pass is complete: Renderer.cpp:70-71
+#if KAJO_STRICT
+                        const F3 term = f3(radiance.x / args.S, radiance.y / args.S, radiance.z / args.S);
+#else
+                        const F3 term = radiance * invS;
+#endif
+                        const int tPass = aheadBy ? aPass : pass, tStolen = aheadBy ? aStolen : stolenFrom;
+                        if (SPLIT) // own or taken over: the term goes to the table, under its pass and pixel
+                            termTable[(tPass - args.firstPass) * 64 + (tStolen >= 0 ? tStolen : lane)] = DFloat4{term.x, term.y, term.z, 0.0f};
+                        else if (tStolen >= 0)
+                            mailbox[tStolen * stealWindow + (tPass - stealBase)] = DFloat4{term.x, term.y, term.z, 0.0f};
+                        else
+                            total = total + term;
+                        radiance = f3(0.0f, 0.0f, 0.0f);
+                        if (aheadBy) { // the issue pass becomes the retiring pass; none of its samples has retired yet
+                            aheadBy = 0;
+                            aLeft = nn;
+                        }
+                    }
+                    const uint32_t s = retired & ringMask;
+                    if (!((doneMask >> s) & 1u))
+                        break;
+                    doneMask &= ~(1u << s);
+                    add = f3(ring[(s * 3 + 0) * 64], ring[(s * 3 + 1) * 64], ring[(s * 3 + 2) * 64]);
+                }
             }
         }
     }
@@ -1437,13 +1484,6 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERN
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBody<false, false>(args, ldsRaw);
-}
-
-// large scenes, cooperative traversal: 8 waves pool and sort their rays every trip (see coopTrace)
-extern "C" __global__ void __launch_bounds__(512, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_COOP(const RenderArgs args)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    renderBody<false, false, false, true>(args, ldsRaw);
 }
 
 // known-answer kernels (kajo_hip_kat_shade / kajo_hip_kat_trace): the SAME device functions, fed rays

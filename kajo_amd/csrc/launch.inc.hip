@@ -20,20 +20,6 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _split_launch)(const RenderArgs* args,
     return (int)hipGetLastError();
 }
 
-// large scenes, cooperative traversal: 512-thread workgroups
-extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _coop_launch)(const RenderArgs* args, unsigned grid, size_t ldsBytes, void* stream)
-{
-    static size_t highWater = 0;
-    if (ldsBytes > highWater) { // (function attribute: only ever raised, see _set_lds)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME_COOP), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-        if (e != hipSuccess)
-            return (int)e;
-        highWater = ldsBytes;
-    }
-    hipLaunchKernelGGL(KAJO_KERNEL_NAME_COOP, dim3(grid), dim3(512), ldsBytes, static_cast<hipStream_t>(stream), *args);
-    return (int)hipGetLastError();
-}
-
 // Dynamic LDS above the 64 KiB default needs an explicit opt-in on the function. The attribute is state of the
 // FUNCTION, shared by every handle of the process: it is only ever raised (a later, smaller scene must not lower the
 // limit under an earlier handle's launches).

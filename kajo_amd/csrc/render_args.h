@@ -20,10 +20,17 @@ struct RenderArgs
     int32_t tileW, tileH, tilesX, tilesY;
     int32_t tileIndex, tileCount, nTilesOwned;
     unsigned long long* counters; // [0] traversals, [1] vertices, [2] lane slots; may be null
-    uint32_t mailboxOffset;       // byte offset of the pass-stealing mailboxes in dynamic LDS (16-byte aligned)
-    int32_t coopKeyMode;          // experiment knob: 0 kind x octant, 1 no sorting (compaction only), 2 kind only, 3 octant only
-    uint32_t coopOffset;          // byte offset of the cooperative-traversal area in dynamic LDS (*_coop kernels only)
+    uint32_t mailboxOffset;       // byte offset of what follows the scene copy in dynamic LDS (16-byte aligned): the SPLIT kernels' term table
     int32_t stealWindow;          // passes at the end of a launch an idle lane may take over (1..KAJO_STEAL_WINDOW_MAX): sizes the mailboxes
+    // Per-wave LDS (integrator.inc.hip renderBody): wave w of the workgroup owns perWaveBytes at perWaveOffset + w * perWaveBytes:
+    //   [0, ringOffset)            mailbox of taken-over passes, 64 lanes x stealWindow x float4   (absent in the SPLIT kernels)
+    //   [ringOffset, stashOffset)  radiances of completed paths waiting for an older path of their lane, ringSlots x 3 x 64 floats
+    //   [stashOffset, ..)          parked vertices, stashDepth x 6 x 64 float4
+    uint32_t perWaveOffset, perWaveBytes, ringOffset, stashOffset;
+    int32_t stashDepth;           // parked vertices per lane: 1, 2 or 4
+    int32_t ringSlots;            // 1, 2, 4 or 8: a lane has at most ringSlots + 1 paths in flight
+    int32_t thrL;                 // the light/BSDF blocks run in a trip when this many lanes have a parked vertex and free registers ...
+    int32_t thrStall;             // ... or this many of them cannot start another camera path
     // Launch-order feedback: blocks are dispatched in blockIdx order; the host sorts them by the cost the
     // previous launch measured (longest first) so that the launch does not end on its most expensive
     // workgroups. Pure scheduling: the buffer slot of a pixel does not depend on it.

@@ -259,22 +259,3 @@ def test_pass_splitting_over_waves_is_bit_invariant(O, scenes, passes):
     want = O.create(sc, 1).render(W, H, S=32, passes=passes, seed=0o715517, depth_limit=8)
     with HipRenderer(sc, W, H, strict=True, passes_per_launch=16) as r:
         assert bits_equal(r.render(passes).radiance(), want)
-
-
-def test_cooperative_sorted_traversal_is_result_identical(O, scenes):
-    """KAJO_FLAG_COOP (an experiment kept for its evidence): the 8 waves of a workgroup pool their rays in
-    LDS every trip, counting-sort them by ray kind and octant into a compact queue, and every lane walks the ray at its queue
-    position. Which lane walks a ray does not change its arithmetic: STRICT stays the oracle bit for bit, FAST stays FAST."""
-    from kajo_amd import capi
-    sc = stress_scene(scenes["spheres_a169"], 300, 6, seed=7)
-    W, H = 128, 64  # 2 x 4 tiles of 64 x 16 = 128 waves: sixteen 8-wave workgroups
-    want = O.create(sc, math=1).render(W, H, S=4, passes=3, seed=SEED, depth_limit=8)
-    with HipRenderer(sc, W, H, spp=4, seed=SEED, strict=True, flags=capi.KAJO_FLAG_COOP, passes_per_launch=2) as r:
-        got = r.render(3).radiance()
-    same = (got[..., :3].view(np.uint32) == want[..., :3].view(np.uint32)) | (np.isnan(got[..., :3]) & np.isnan(want[..., :3]))
-    assert same.all()
-    with HipRenderer(sc, W, H, spp=16, seed=SEED, flags=capi.KAJO_FLAG_COOP) as r:
-        a = r.render(2).radiance()
-    with HipRenderer(sc, W, H, spp=16, seed=SEED) as r:
-        b = r.render(2).radiance()
-    assert bits_equal(a, b)

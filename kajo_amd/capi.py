@@ -25,7 +25,8 @@ KAJO_FLAG_COUNTERS = 2
 KAJO_FLAG_NO_GRID = 4
 KAJO_FLAG_NO_REORDER = 8
 KAJO_FLAG_NO_SPLIT = 16
-KAJO_FLAG_COOP = 32
+KAJO_FLAG_COOP = 32      # experiment library libkajo_hip_r02.so only
+KAJO_FLAG_DEFERRED = 64  # experiment library libkajo_hip_exp.so only
 
 # every symbol include/kajo_hip.h declares
 EXPORTS = [

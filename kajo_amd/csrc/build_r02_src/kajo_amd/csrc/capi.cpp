@@ -27,10 +27,8 @@ int kajo_render_fast_launch(const RenderArgs*, int coldInLds, unsigned grid, uns
 int kajo_render_strict_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_fast_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_strict_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
-#ifdef KAJO_WITH_DEFERRED
-int kajo_render_fast_deferred_launch(const RenderArgs*, int kind, unsigned grid, unsigned block, size_t lds, void* stream);
-int kajo_render_strict_deferred_launch(const RenderArgs*, int kind, unsigned grid, unsigned block, size_t lds, void* stream);
-#endif
+int kajo_render_fast_coop_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
+int kajo_render_strict_coop_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_render_fast_set_lds(int coldInLds, size_t lds);
 int kajo_render_strict_set_lds(int coldInLds, size_t lds);
 int kajo_resolve_fast_launch(const void* frame, int count, float passes, void* dst, void* stream);
@@ -114,27 +112,8 @@ struct KajoHip
                                 // independently (measured +2.3 % over 4-wave groups)
     int passesDone = 0;
     size_t ldsBytes = 0, hotBytes = 0;
+    bool coop = false;   // large scenes: 512-thread workgroups with a pooled, sorted ray queue (integrator.inc.hip coopTrace)
     int stealWindow = 4; // render_args.h; 1 when a large scene needs the LDS for its grid
-    // parked vertices and out-of-order completion (integrator.inc.hip renderBody, render_args.h)
-    // EXPERIMENT (KAJO_FLAG_DEFERRED, experiment library only): parked vertices and out-of-order completion (deferred.inc.hip)
-    bool deferred = false;
-    int stashDepth = 0, ringSlots = 0, thrL = 0, thrStall = 0;
-    int ldsExtra = 0; // KAJO_LDS_EXTRA: unused bytes per wave, to study a launch at a lower occupancy (diagnostic)
-    size_t perWaveBytes(bool withMailbox) const
-    {
-        return (size_t)ldsExtra + (withMailbox ? (size_t)64 * stealWindow * 16 : 0) + (size_t)ringSlots * 3 * 64 * 4 + (size_t)stashDepth * 6 * 64 * 16;
-    }
-    void fillWaveLds(RenderArgs& a, size_t perWaveOffset, bool withMailbox) const
-    {
-        a.perWaveOffset = (uint32_t)perWaveOffset;
-        a.perWaveBytes = (uint32_t)perWaveBytes(withMailbox);
-        a.ringOffset = withMailbox ? (uint32_t)(64 * stealWindow * 16) : 0u;
-        a.stashOffset = a.ringOffset + (uint32_t)(ringSlots * 3 * 64 * 4);
-        a.stashDepth = stashDepth;
-        a.ringSlots = ringSlots;
-        a.thrL = thrL;
-        a.thrStall = thrStall;
-    }
     int coldInLds = 1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // kernel timing
     std::vector<hipEvent_t> eventPool;
@@ -293,14 +272,8 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         p.tileCount = 1;
     if (p.samplesPerPass < 1 || p.samplesPerPass > 65535)
         return fail(KAJO_E_INVALID, "samplesPerPass must be in [1, 65535]");
-    if (p.flags & KAJO_FLAG_COOP)
-        return fail(KAJO_E_INVALID, "KAJO_FLAG_COOP: the cooperative-traversal experiment is not built into this library (make -C kajo_amd/csrc experiments)");
-#ifndef KAJO_WITH_DEFERRED
-    if (p.flags & KAJO_FLAG_DEFERRED)
-        return fail(KAJO_E_INVALID, "KAJO_FLAG_DEFERRED: the deferred-shading experiment is not built into this library (make -C kajo_amd/csrc experiments)");
-#endif
-    if (p.depthLimit < 0 || p.depthLimit > 1000) // (a parked vertex carries its depth in 10 bits; the reference's limit is 8)
-        return fail(KAJO_E_INVALID, "depthLimit must be in [0, 1000]");
+    if (p.depthLimit < 0)
+        return fail(KAJO_E_INVALID, "depthLimit must be >= 0");
     if (p.tileW < 8 || p.tileH < 8 || (p.tileW & 7) || (p.tileH & 7) || (p.tileW * p.tileH) % 256)
         return fail(KAJO_E_INVALID, "tile size must be multiples of 8 with tileW*tileH a multiple of 256");
     if (p.tileCount < 1 || p.tileIndex < 0 || p.tileIndex >= p.tileCount)
@@ -381,89 +354,38 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     const size_t hotBytes = (size_t)v.nPlanes * (16 + 4) + (size_t)v.nSphereHot * 16 + (size_t)v.nSpheres * 4;
     const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * sizeof(DMaterial) +
                              (size_t)v.nLights * 4;
-    // What every wave adds to the scene copy (render_args.h): the mailbox of taken-over passes (and, in the deferred-shading
-    // experiment, the ring of completed paths and the stash of parked vertices). Every size is a tuning knob (KAJO_STEAL_WINDOW;
-    // KAJO_STASH_DEPTH, KAJO_RING_SLOTS, KAJO_THR_L, KAJO_THR_STALL), applied BEFORE the LDS budget is checked.
-    auto envInt = [](const char* name, int lo, int hi, int& v) {
-        if (const char* e = std::getenv(name)) {
-            const int x = std::atoi(e);
-            if (x >= lo && x <= hi)
-                v = x;
-        }
-    };
-    auto pow2 = [](int x) { return x > 0 && (x & (x - 1)) == 0; };
-    const bool big = st.gridEnabled || hotBytes + coldBytes > 40 * 1024;
-    h->deferred = (p.flags & KAJO_FLAG_DEFERRED) != 0;
-    h->stealWindow = 4;
-    if (h->deferred) {
-        if (big) { // the walk dominates and wants its occupancy: the light / BSDF blocks run in every trip
-            h->stashDepth = 1;
-            h->ringSlots = 1;
-            h->thrL = 1;
-            h->thrStall = 1;
-        } else {
-            h->stealWindow = 2;
-            h->stashDepth = 1;
-            h->ringSlots = 2;
-            h->thrL = 32;
-            h->thrStall = 8;
-        }
-    }
-    envInt("KAJO_STEAL_WINDOW", 1, 16, h->stealWindow);
-    envInt("KAJO_LDS_EXTRA", 0, 64 * 1024, h->ldsExtra);
-    h->ldsExtra &= ~15;
-    if (h->deferred) {
-        envInt("KAJO_STASH_DEPTH", 1, 4, h->stashDepth);
-        envInt("KAJO_RING_SLOTS", 1, 8, h->ringSlots);
-        envInt("KAJO_THR_L", 1, 65, h->thrL);
-        envInt("KAJO_THR_STALL", 1, 65, h->thrStall);
-    }
-    if (h->deferred && (!pow2(h->stashDepth) || !pow2(h->ringSlots))) {
-        destroy(h);
-        return fail(KAJO_E_INVALID, "KAJO_STASH_DEPTH and KAJO_RING_SLOTS must be powers of two");
-    }
     size_t gridBytes = 0;
     if (st.gridEnabled) {
         gridBytes = ((st.gridCellStart.size() * sizeof(uint32_t) + st.gridItems.size() * sizeof(uint16_t)) + 15) & ~(size_t)15;
         // The DDA reads a cell record and an item per step, each a dependent load: ~64 cycles from LDS, ~500 from L2. But the
-        // walk is latency-bound and wants its workgroups per CU (measured on the 1000-sphere scene in round 2: the grid in LDS
-        // at three workgroups per CU is 12 % SLOWER than the grid in L2 at four), so the grid moves into LDS only while hot
-        // records + grid + the four waves' areas stay within the limit.
+        // walk is latency-bound and wants its four workgroups per CU (measured on the 1000-sphere scene: the grid in LDS at
+        // three workgroups per CU is 12 % SLOWER than the grid in L2 at four), so the grid moves into LDS only while hot
+        // records + grid + mailboxes stay within 40 KiB -- with the mailboxes shrunk to a one-pass steal window if need be.
         size_t gridLimit = 40 * 1024;
-        if (const char* e = std::getenv("KAJO_GRID_LDS_LIMIT")) { // tuning knob, bytes
-            const long x = std::atol(e);
-            gridLimit = x < 0 ? 0 : (x > 160 * 1024 ? 160 * 1024 : (size_t)x);
-        }
-        // ... with the mailboxes shrunk to a one-pass steal window if need be
-        const int wanted = h->stealWindow;
+        if (const char* e = std::getenv("KAJO_GRID_LDS_LIMIT")) // tuning knob, bytes
+            gridLimit = (size_t)std::atol(e);
         for (int window : {4, 2, 1}) {
-            if (window > wanted)
-                continue;
-            h->stealWindow = window;
-            if (hotBytes + gridBytes + 4 * h->perWaveBytes(true) <= gridLimit) {
+            if (hotBytes + gridBytes + (size_t)4 * 64 * window * 16 <= gridLimit) {
                 v.grid.inLds = 1;
+                h->stealWindow = window;
                 break;
             }
         }
-        if (!v.grid.inLds) {
-            h->stealWindow = wanted;
+        if (!v.grid.inLds)
             gridBytes = 0;
-        }
     }
     h->hotBytes = hotBytes + gridBytes; // what the big-scene staging (and the known-answer kernels) put in LDS
-    h->coldInLds = !big;
+    h->coldInLds = hotBytes + coldBytes <= 40 * 1024 && !st.gridEnabled;
     h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0) + gridBytes;
-    // every workgroup stages its own LDS copy of the scene: single-wave groups only while that copy is small
-    h->wavesPerBlock = h->ldsBytes <= 6 * 1024 ? 1 : 4;
-    if (const char* e = std::getenv("KAJO_WAVES_PER_BLOCK")) { // tuning knob: 1, 2 or 4
-        const int w = std::atoi(e);
-        if (w == 1 || w == 2 || w == 4)
-            h->wavesPerBlock = (unsigned)w;
-    }
-    // the one check, with the final values: scene copy + the waves' areas must fit a CU
-    if (((h->ldsBytes + 15) & ~(size_t)15) + (size_t)h->wavesPerBlock * h->perWaveBytes(true) > 160 * 1024) {
+    // scene copy + the pass-stealing mailboxes of a 4-wave workgroup (64 lanes x 4 passes x float4 per wave) must fit a CU
+    if (((h->ldsBytes + 15) & ~(size_t)15) + (size_t)4 * 64 * h->stealWindow * 16 > 160 * 1024) {
         destroy(h);
-        return fail(KAJO_E_INVALID, "scene exceeds the LDS staging limit: scene records + the waves' mailbox / ring / stash areas must fit 160 KiB");
+        return fail(KAJO_E_INVALID, "scene exceeds the LDS staging limit: hot records + 16 KiB of mailboxes must fit 160 KiB");
+    }
+    if (const char* e = std::getenv("KAJO_STEAL_WINDOW")) { // tuning knob: passes at the end of a launch an idle lane may take over
+        const int w = std::atoi(e);
+        if (w >= 1 && w <= 16 && !st.gridEnabled)
+            h->stealWindow = w;
     }
     // ---- tiles -----------------------------------------------------------------------------
     TileMap& m = h->map;
@@ -489,6 +411,28 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     }
     {
         const int wavesPerTile = (p.tileW / 8) * (p.tileH / 8);
+        // every workgroup stages its own LDS copy of the scene: single-wave groups only while that copy is small
+        h->wavesPerBlock = h->ldsBytes <= 6 * 1024 ? 1 : 4;
+        if (const char* e = std::getenv("KAJO_WAVES_PER_BLOCK")) { // tuning knob: 1, 2 or 4
+            const int w = std::atoi(e);
+            if (w == 1 || w == 2 || w == 4)
+                h->wavesPerBlock = (unsigned)w;
+        }
+        // EXPERIMENT, opt-in (KAJO_FLAG_COOP or KAJO_COOP=1): scenes walked through the grid, 8 waves per workgroup pool, sort and
+        // compact their rays every trip (integrator.inc.hip coopTrace). Results are identical; it is SLOWER (C5: 1.45 against
+        // 2.04 G paths/s -- the lockstep of the 8 waves costs more than the compaction gains, and sorting by ray kind and octant
+        // does not make a wave's rays coherent enough to matter: DESIGN.md section 8). Needs the wave count of the owned tiles to
+        // be a multiple of 8 and its LDS (scene + 8 mailboxes + 25 KiB of queue) twice per CU.
+        bool coop = (p.flags & KAJO_FLAG_COOP) != 0;
+        if (const char* e = std::getenv("KAJO_COOP")) // tuning knob: 0 / 1
+            coop = std::atoi(e) != 0;
+        coop = coop && st.gridEnabled && !h->coldInLds && ((long long)h->nTilesOwned * wavesPerTile) % 8 == 0;
+        if (coop && ((h->ldsBytes + 15) & ~(size_t)15) + (size_t)8 * 64 * h->stealWindow * 16 + 1024 + 64 + 512 * 48 > 80 * 1024)
+            coop = false;
+        if (coop) {
+            h->coop = true;
+            h->wavesPerBlock = 8;
+        }
         h->gridBlocks = (unsigned)((long long)h->nTilesOwned * wavesPerTile / h->wavesPerBlock);
         if (h->gridBlocks && !(p.flags & KAJO_FLAG_NO_REORDER)) {
             CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->waveTrips), (size_t)h->gridBlocks * h->wavesPerBlock * sizeof(uint32_t)));
@@ -496,7 +440,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         }
     }
     {
-        const size_t ldsTotal = ((h->ldsBytes + 15) & ~(size_t)15) + (size_t)h->wavesPerBlock * h->perWaveBytes(true);
+        const size_t ldsTotal = ((h->ldsBytes + 15) & ~(size_t)15) + (size_t)h->wavesPerBlock * 64 * h->stealWindow * 16;
         if (ldsTotal > 48 * 1024) {
             CREATE_TRY((hipError_t)(h->strict() ? kajo_render_strict_set_lds(h->coldInLds, ldsTotal)
                                                 : kajo_render_fast_set_lds(h->coldInLds, ldsTotal)));
@@ -572,9 +516,14 @@ int kajo_hip_render(kajo_hip_t h, int passes)
     const unsigned grid = h->gridBlocks;
     a.blockOrder = h->orderValid ? h->blockOrder : nullptr;
     a.waveTrips = (h->waveTrips && !h->orderValid) ? h->waveTrips : nullptr; // measure once, on the first launch
-    // scene copy + every wave's mailbox, ring and stash
-    h->fillWaveLds(a, a.mailboxOffset, true);
-    const size_t ldsTotal = a.mailboxOffset + (size_t)h->wavesPerBlock * a.perWaveBytes;
+    // scene copy + one mailbox (64 lanes x 4 passes x float4) per wave of the workgroup
+    size_t ldsTotal = a.mailboxOffset + (size_t)h->wavesPerBlock * 64 * h->stealWindow * 16;
+    if (h->coop) {
+        a.coopOffset = (uint32_t)ldsTotal;
+        if (const char* e = std::getenv("KAJO_COOP_KEY")) // experiment knob
+            a.coopKeyMode = std::atoi(e);
+        ldsTotal += 1024 + 64 + 512 * 48; // bucket counters, wave totals, 512 rays (2 x float4), 512 hits (float4)
+    }
     const int perLaunch = p.passesPerLaunch > 0 ? p.passesPerLaunch : 16;
     int left = passes;
     while (left > 0) {
@@ -589,7 +538,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         // block and divide the passes of the launch (when they divide evenly); the per-pass terms meet in LDS.
         unsigned split = 1;
         const unsigned long long pixelBlocks = (unsigned long long)grid * h->wavesPerBlock;
-        if (h->coldInLds && !(p.flags & KAJO_FLAG_NO_SPLIT) && !h->deferred) {
+        if (h->coldInLds && !(p.flags & KAJO_FLAG_NO_SPLIT)) {
             // measured (tools/size_sweep.py with KAJO_SPLIT=1..16, 256x144 ... 1920x1080): frames of fewer than three
             // rounds of the 4096 wave slots run best with the largest power of two -- up to 16 waves per block, as far
             // as the passes divide -- that keeps the launch within 8 rounds: many short waves pack the tail of the
@@ -602,22 +551,19 @@ int kajo_hip_render(kajo_hip_t h, int passes)
                     split = (unsigned)v;
             }
         }
-        while (split > 1 && a.mailboxOffset + (size_t)now * 64 * 16 + split * h->perWaveBytes(false) > 48 * 1024)
-            split /= 2; // the table and the waves' areas would need the large-LDS opt-in: not worth it
+        if (a.mailboxOffset + (size_t)now * 64 * 16 > 48 * 1024) // the table would need the large-LDS opt-in: not worth it
+            split = 1;
         hipError_t le;
         if (split > 1) {
             RenderArgs b = a;
             b.blockOrder = nullptr; // one round or two: the launch order does not matter
             b.waveTrips = nullptr;
-            h->fillWaveLds(b, a.mailboxOffset + (size_t)now * 64 * 16, false); // behind the [pass][pixel] term table
-            const size_t ldsSplit = b.perWaveOffset + (size_t)split * b.perWaveBytes;
+            const size_t ldsSplit = a.mailboxOffset + (size_t)now * 64 * 16;
             le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream)
                                           : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream));
-#ifdef KAJO_WITH_DEFERRED
-        } else if (h->deferred) {
-            le = (hipError_t)(h->strict() ? kajo_render_strict_deferred_launch(&a, h->coldInLds ? 0 : 1, grid, block, ldsTotal, h->stream)
-                                          : kajo_render_fast_deferred_launch(&a, h->coldInLds ? 0 : 1, grid, block, ldsTotal, h->stream));
-#endif
+        } else if (h->coop) {
+            le = (hipError_t)(h->strict() ? kajo_render_strict_coop_launch(&a, grid, ldsTotal, h->stream)
+                                          : kajo_render_fast_coop_launch(&a, grid, ldsTotal, h->stream));
         } else {
             le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream)
                                           : kajo_render_fast_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream));
@@ -882,21 +828,9 @@ int kajo_hip_kat_shade(kajo_hip_t h, int n, const float* origins, const float* d
     a.katFinal = static_cast<uint64_t*>(dFinal.p);
     a.katCount = n;
     a.stealWindow = 1;
-    a.mailboxOffset = (uint32_t)((h->hotBytes + 15) & ~(size_t)15);
-    h->fillWaveLds(a, a.mailboxOffset, false);
-    const size_t ldsKat = a.mailboxOffset + 4 * (size_t)a.perWaveBytes;
-    if (ldsKat > 64 * 1024)
-        return fail(KAJO_E_INVALID, "known-answer entry points are limited to scenes whose hot records fit 48 KiB of LDS");
     const unsigned grid = (unsigned)((n + 255) / 256);
-    hipError_t le;
-#ifdef KAJO_WITH_DEFERRED
-    if (h->deferred)
-        le = (hipError_t)(h->strict() ? kajo_render_strict_deferred_launch(&a, 2, grid, 256, ldsKat, h->stream)
-                                      : kajo_render_fast_deferred_launch(&a, 2, grid, 256, ldsKat, h->stream));
-    else
-#endif
-    le = (hipError_t)(h->strict() ? kajo_kat_shade_strict_launch(&a, grid, ldsKat, h->stream)
-                                  : kajo_kat_shade_fast_launch(&a, grid, ldsKat, h->stream));
+    hipError_t le = (hipError_t)(h->strict() ? kajo_kat_shade_strict_launch(&a, grid, h->hotBytes, h->stream)
+                                             : kajo_kat_shade_fast_launch(&a, grid, h->hotBytes, h->stream));
     if (le != hipSuccess)
         return failHip(le, "kat shade launch");
     std::vector<float> out4((size_t)n * 4);

@@ -1,0 +1,101 @@
+// device_scene.h -- the render-ready scene as the HIP kernels read it.
+//
+// Counterpart of cpu::Scene (renderer/cpu/Scene.h:16-59: per object `matrix`, `invMatrix`,
+// `determinant`, material, radius), re-laid for wave64 execution: every lane of a wave tests
+// the same primitive at the same time, so the records the closest-hit loop touches ("hot")
+// are packed small and staged into LDS where one broadcast read serves 64 lanes; data that
+// only the winning hit needs ("cold": shading frames, materials) is fetched per lane
+// afterwards.
+//
+//   plane   hot  float4 row   = row y of inverse(M): (inv[0][1], inv[1][1], inv[2][1], inv[3][1])
+//                               -- the only row Raytracer.cpp:74-98 uses (local plane y = 0)
+//                float  det
+//           cold float4 x 3   = world normal, tangent, binormal (constants of the plane)
+//   sphere  hot  translated:  float4 (cx, cy, cz, r*r)          when M is a pure translation
+//                general:     3 x float4 rows of inverse(M) + float4 (r*r, det, 0, 0)
+//           cold DSphereCold  = centre M*(0,0,0,1), radius, mat3(M)
+//   material     DMaterial    = scene::Material (scene/Scene.h:11-23) + the three
+//                               per-material coin probabilities of Shader.cpp:124,130-134,153
+//
+// A pure translation makes inverse(M) = translate(-c) and det = 1 exactly, so the translated
+// record gives bit-identical t, normal and position to the general formula.
+#ifndef KAJO_DEVICE_SCENE_H
+#define KAJO_DEVICE_SCENE_H
+
+#include <stdint.h>
+
+struct DFloat4
+{
+    float x, y, z, w;
+};
+
+struct DMaterial // 24 floats
+{
+    float diffuse[3];
+    float pRR;      // max over rgb of max(diffuse, specular, transparency)   (Shader.cpp:124-125)
+    float specular[3];
+    float pT;       // sum(transparency) / (sum d + sum s + sum t)            (Shader.cpp:130-133)
+    float emission[3];
+    float pD;       // sum(diffuse) / (sum d + sum s)                         (Shader.cpp:153)
+    float transparency[3];
+    float exponent;
+    float ior;
+    uint32_t isLight; // emission != vec4(0)                                  (Shader.cpp:57)
+    // FAST numerics only: the path-weight scales of Shader.cpp:146-147,160-177, which depend only on
+    // the material and on which way the coins fell
+    float sTransparent; // 1 / (pRR * pT)
+    float sDiffuse;     // 1 / (pRR * (1 - pT) * pD)
+    float sSpecular;    // 1 / (pRR * (1 - pT) * (1 - pD))
+    float sStop;        // 1 / (1 - pRR): Russian roulette said stop
+    float sDepth;       // 1 / pRR: depth limit reached
+    float pad;
+};
+
+struct DSphereCold // 16 floats
+{
+    float cx, cy, cz, radius;
+    float m[9];     // mat3(M), m[3*row + col]: world = m * object
+    uint32_t general;
+    float invRadius;    // 1 / radius                       (FAST numerics only)
+    float invTwoPiR2;   // 1 / (2 pi radius^2): light pdf    (FAST numerics only)
+};
+
+// sphereHotOffset[i]: index of the sphere's first float4 in the hot array; bit 31 set = general
+#define KAJO_SPHERE_GENERAL 0x80000000u
+
+// Uniform grid over the spheres (large scenes): a conservative culling structure. A ray visits the
+// cells it crosses front to back (3D-DDA) and runs the SAME per-sphere intersection arithmetic on
+// the spheres registered in each cell; the closest hit, and the "later object wins" tie rule of
+// Raytracer.cpp:108-124, are those of the brute-force walk. Planes are always tested one by one.
+struct DGrid
+{
+    int32_t enabled;
+    int32_t dim[3];
+    float bmin[3], bmax[3];
+    float cell[3], invCell[3];
+    const uint32_t* cellStart; // [dim.x * dim.y * dim.z + 1]
+    const uint16_t* items;     // sphere indices (16 bits: the hot records of 65536 spheres would not fit LDS anyway), ascending within a cell
+    int32_t nCells, nItems;
+    int32_t inLds;             // the two arrays are staged into LDS behind the hot records
+};
+
+struct DSceneView // device pointers + counts, passed to the kernels by value
+{
+    const DFloat4* planeRow;    // [nPlanes]
+    const float* planeDet;      // [nPlanes]
+    const DFloat4* planeFrame;  // [3 * nPlanes] normal, tangent, binormal
+    const DFloat4* sphereHot;   // [nSphereHot]
+    const uint32_t* sphereHotOffset; // [nSpheres]
+    const DSphereCold* sphereCold;   // [nSpheres]
+    const DMaterial* material;  // [nPlanes + nSpheres], index = object id - 1
+    const int32_t* light;       // [nLights] sphere indices, scene order
+    int32_t nPlanes, nSpheres, nSphereHot, nLights;
+    int32_t allTranslated;      // every sphere uses the 1-float4 record
+    int32_t planesRigid;        // every plane has |determinant - 1| <= 2^-20 (FAST numerics only)
+    float background[3];
+    DGrid grid;
+    // camera (Renderer.cpp:29-34): p1, p2 - p1, p3 - p1, origin
+    float p1[3], dp2[3], dp3[3], origin[3];
+};
+
+#endif

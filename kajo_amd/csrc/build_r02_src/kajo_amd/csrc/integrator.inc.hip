@@ -59,16 +59,30 @@ KDEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 
 // ---- numerics policy ------------------------------------------------------------------
 #if KAJO_STRICT
+#ifdef KAJO_X_APPROX_DIVSQRT
+// TIMING EXPERIMENT ONLY (not bit-exact): what the correctly rounded divisions and square roots cost the STRICT kernels
+KDEV float kdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+KDEV float ksqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
+KDEV float krcp(float a) { return __builtin_amdgcn_rcpf(a); }
+#else
 KDEV float kdiv(float a, float b) { return a / b; }
 KDEV float ksqrt(float a) { return __builtin_sqrtf(a); }
 KDEV float krcp(float a) { return 1.0f / a; }
+#endif
 KDEV float kpow(float x, float y) { return kajo_powf(x, y); }
 #else
-// FAST: the hardware's 1-ulp reciprocal, square root and reciprocal square root (profiles/r01_hwmath_accuracy.txt; swapping in
-// the correctly rounded operations does not move the pixels where FAST and the oracle part: profiles/r01_flip_experiment.txt).
+// FAST: the hardware's 1-ulp reciprocal, square root and reciprocal square root (profiles/r01_hwmath_accuracy.txt).
+// -DKAJO_X_IEEE swaps in the correctly rounded operations: an experiment (tools/flip_experiment.sh) showing that the
+// pixels where FAST and the oracle part do not come from these approximations.
+#ifdef KAJO_X_IEEE
+KDEV float krcp(float a) { return 1.0f / a; }
+KDEV float ksqrt(float a) { return __builtin_sqrtf(a); }
+KDEV float krsq(float a) { return 1.0f / __builtin_sqrtf(a); }
+#else
 KDEV float krcp(float a) { return __builtin_amdgcn_rcpf(a); }
 KDEV float ksqrt(float a) { return __builtin_amdgcn_sqrtf(a); }
 KDEV float krsq(float a) { return __builtin_amdgcn_rsqf(a); }
+#endif
 KDEV float kdiv(float a, float b) { return a * krcp(b); }
 // x >= 0 (clamped cosine / uniform variate / clamped colour): x^y = 2^(y log2 x); v_log(0) = -inf
 // gives 2^-inf = 0 for y > 0, and y == 0 is answered explicitly as libm does (pow(x, 0) = 1)
@@ -96,7 +110,9 @@ KDEV float kmax0(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, 1.0f); }
 KDEV F3 normalize(F3 a)
 {
     float sqr = a.x * a.x + a.y * a.y + a.z * a.z;
-#if KAJO_STRICT
+#if KAJO_STRICT && defined(KAJO_X_APPROX_DIVSQRT)
+    return a * __builtin_amdgcn_rsqf(sqr);
+#elif KAJO_STRICT
     return a * (1.0f / __builtin_sqrtf(sqr)); // glm: x * inversesqrt(dot), inversesqrt = 1 / sqrt
 #else
     return a * krsq(sqr);
@@ -408,6 +424,27 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
         // the smaller non-negative root is the smaller bit pattern of the two (see above: a negative root and
         // the NaN of a negative discriminant sort above every acceptable value), so "no root, both behind,
         // beyond the closest so far" is again one unsigned compare.
+#ifdef KAJO_X_REFROOTS
+        // experiment (tools/flip_experiment.sh, with -ffp-contract=off): the reference's own root formulas
+        // (Raytracer.cpp:26-44) in the FAST walk -- do the FAST-vs-oracle path flips come from the root formulas?
+        for (int i = 0; i < ns; i++) {
+            const DFloat4 s = lds.sphereHot[i];
+            F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+            float b = 2 * dot(d, o);
+            float c = dot(o, o) - s.w;
+            float discr = b * b - 4 * aT * c;
+            float sq = __builtin_sqrtf(discr);
+            float q = (b < 0.0f) ? (-b - sq) * .5f : (-b + sq) * .5f;
+            float t0 = q / aT, t1 = c / q;
+            bool sw = t0 > t1;
+            float lo = sw ? t1 : t0, hi = sw ? t0 : t1;
+            float th = (lo < 0.0f) ? hi : lo;
+            bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(th > tMax || th < 0.0f);
+            tMax = ok ? th : tMax;
+            best = ok ? np + 1 + i : best;
+        }
+        return Hit{best, tMax, tMax};
+#endif
         const float tPlane = tMax;
         kMax = __builtin_bit_cast(uint32_t, tMax * aT);
         idV = (uint32_t)np + 1;
@@ -711,6 +748,9 @@ enum : int
 
 } // namespace
 
+// passes at the end of a launch that an idle lane may take over: RenderArgs::stealWindow, at most 4 (64 lanes x 4 float4 = 4 KiB
+// of mailbox per wave; large scenes that need the LDS for their grid run with 1)
+
 #ifndef KAJO_WAVES_PER_SIMD
 #define KAJO_WAVES_PER_SIMD 4 // register budget: 512 / 4 = 128 VGPRs per lane
 #endif
@@ -789,6 +829,79 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     return lds;
 }
 
+// ---- cooperative traversal (large scenes, *_coop kernels) --------------------------------------------------------------
+// A walk of the grid costs a wave as much as its LONGEST ray times the FULLEST cell among its 64 lanes; the rays a wave's lanes
+// hold at one moment -- a camera ray here, a shadow ray to light 3 there, an extension ray -- share neither. Coherent rays are
+// ~5x cheaper (measured: camera rays alone walk the 1000-sphere grid at 41 G rays/s, the mix at 7.7). So the 8 waves of a
+// workgroup pool their rays every trip: each lane publishes its ray in LDS under a key (kind of ray: camera / extension /
+// shadow ray to light k; direction octant), a counting sort over the 256 keys (LDS atomics for the rank inside a bucket, a
+// wave scan for the bucket offsets) lines them up, every lane traces the ray at ITS position of the sorted queue and writes
+// the hit to the owner's slot. Lanes without a ray take no queue position: the queue is compact and the waves behind its
+// end skip the walk. A ray is traced by the same arithmetic whichever lane walks it, so every result is the one the
+// owner would have computed: STRICT stays bit-identical to the oracle.
+struct CoopLds
+{
+    uint32_t* counts;   // [256] bucket counts, then exclusive offsets
+    uint32_t* waveTot;  // [4]
+    DFloat4* rays;      // [2 * 512]: (O, owner), (d, -)
+    DFloat4* hits;      // [512]: id, t, t0
+};
+
+KDEV CoopLds coopLds(unsigned char* ldsRaw, uint32_t offset)
+{
+    CoopLds c;
+    c.counts = reinterpret_cast<uint32_t*>(ldsRaw + offset);
+    c.waveTot = c.counts + 256;
+    c.rays = reinterpret_cast<DFloat4*>(ldsRaw + offset + 1024 + 64);
+    c.hits = c.rays + 2 * 512;
+    return c;
+}
+
+// All 512 threads of the workgroup call this together, once per trip (five barriers inside, none in divergent code).
+template <bool GRID>
+KDEV Hit coopTrace(const DSceneView& sc, const LdsScene& lds, const CoopLds& co, bool hasRay, uint32_t key, F3 O, F3 d)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    key = hasRay ? key : 255u;
+    const uint32_t rank = atomicAdd(&co.counts[key], 1u); // (zeroed before the trip's first barrier)
+    __syncthreads();
+    uint32_t v = 0, incl = 0;
+    if (tid < 256u) { // waves 0..3, whole waves
+        v = co.counts[tid];
+        incl = v;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t t = __shfl_up(incl, o);
+            incl += lane >= (uint32_t)o ? t : 0u;
+        }
+        if (lane == 63u)
+            co.waveTot[wave] = incl;
+    }
+    __syncthreads();
+    if (tid < 256u) {
+        uint32_t base = 0;
+        for (uint32_t w = 0; w < wave; w++)
+            base += co.waveTot[w];
+        co.counts[tid] = base + incl - v; // exclusive offset of bucket tid
+    }
+    __syncthreads();
+    if (hasRay) {
+        const uint32_t pos = co.counts[key] + rank;
+        co.rays[2 * pos] = DFloat4{O.x, O.y, O.z, __builtin_bit_cast(float, tid)};
+        co.rays[2 * pos + 1] = DFloat4{d.x, d.y, d.z, 0.0f};
+    }
+    __syncthreads();
+    const uint32_t nRays = co.counts[255]; // bucket 255 holds the lanes without a ray: its offset is the queue length
+    if (tid < nRays) {
+        const DFloat4 ro = co.rays[2 * tid], rd = co.rays[2 * tid + 1];
+        const Hit h = trace<GRID>(sc, lds, f3(ro.x, ro.y, ro.z), f3(rd.x, rd.y, rd.z));
+        co.hits[__builtin_bit_cast(uint32_t, ro.w)] = DFloat4{__builtin_bit_cast(float, h.id), h.t, h.t0, 0.0f};
+    }
+    __syncthreads();
+    const DFloat4 r = co.hits[tid];
+    return hasRay ? Hit{__builtin_bit_cast(int, r.x), r.y, r.z} : Hit{0, 0.0f, 0.0f};
+}
+
 // KAT (known-answer mode): instead of its pixel's camera paths a lane runs ONE path from a given ray
 // and RNG state and reports its radiance and the RNG state it ends in (kajo_hip_kat_shade).
 //
@@ -796,7 +909,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
 // them, so that a frame with fewer blocks than the chip has wave slots still fills it. Every pass's term radiance / S
 // goes to an LDS table [pass][pixel]; after a barrier wave 0 adds the terms to the accumulation in pass order -- the
 // float sums are those of one wave doing all the passes.
-template <bool COLD_LDS, bool KAT, bool SPLIT = false>
+template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool COOP = false>
 KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 {
     const DSceneView& sc = args.scene;
@@ -805,9 +918,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
 
-    // per-wave mailbox for taken-over passes: [lane][stealWindow] float4, behind the scene copy (render_args.h)
+    // per-wave mailbox for taken-over passes: [lane][stealWindow] float4, behind the scene copy
     const int stealWindow = args.stealWindow;
-    DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.perWaveOffset + (threadIdx.x >> 6) * args.perWaveBytes);
+    DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.mailboxOffset) + (threadIdx.x >> 6) * (64 * stealWindow);
+
+    const CoopLds coop = coopLds(ldsRaw, COOP ? args.coopOffset : 0u);
 
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;
@@ -1033,16 +1148,42 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 mode = MODE_EXTEND;
             }
         }
-        {
-            const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
-            if (aliveMask == 0ull)
+        if (COOP) {
+            // the workgroup's waves make their trips together: the loop ends when no lane of any wave has work left
+            if (threadIdx.x < 256u)
+                coop.counts[threadIdx.x] = 0u;
+            if (!__syncthreads_or(mode != MODE_DONE))
                 break;
+            __syncthreads(); // (the zeroed counters are in place before the first atomic, whatever the reduction does inside)
+        } else {
+#ifdef KAJO_X_LOCKSTEP
+            // TIMING EXPERIMENT ONLY: what would it cost to keep the waves of a workgroup in step (one barrier per trip, the
+            // workgroup makes as many trips as its slowest wave) -- the precondition of any exchange of work between them?
+            if (!SPLIT && !KAT) {
+                if (!__syncthreads_or(mode != MODE_DONE))
+                    break;
+            } else
+#endif
+            {
+                const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
+                if (aliveMask == 0ull)
+                    break;
+            }
         }
         const unsigned long long activeMask = __ballot(mode == MODE_EXTEND || mode == MODE_SHADOW); // lanes with a ray
 
         KAJO_STAMP(0); // camera-ray block
         // ---- one ray per lane through the whole scene ------------------------------------------
-        const Hit hit = trace<!COLD_LDS>(sc, lds, O, d);
+        Hit hit;
+        if (COOP) {
+            // key: what kind of ray (camera 0, extension 1, shadow ray to light k: 2 + k, capped) x direction octant
+            const uint32_t kind = mode == MODE_SHADOW ? 2u + (uint32_t)(lightK < 28 ? lightK : 28) : ((depth == 0 && !pendBsdf) ? 0u : 1u);
+            const uint32_t octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+            const uint32_t key = args.coopKeyMode == 0 ? kind * 8u + octant : (args.coopKeyMode == 1 ? 0u : (args.coopKeyMode == 2 ? kind : octant));
+            hit = coopTrace<!COLD_LDS>(sc, lds, coop, mode == MODE_EXTEND || mode == MODE_SHADOW, key, O, d);
+        } else {
+            hit = trace<!COLD_LDS>(sc, lds, O, d);
+        }
         KAJO_STAMP(1); // traversal
         if (counting) {
             ctrTraversals += __builtin_popcountll(activeMask);
@@ -1098,9 +1239,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 float pc;
                 const bool cont = flipCoin(rng, m.pRR, pc); // Shader.cpp:124-125
                 if (!cont || depth >= args.depthLimit) {
-                    // Shader.cpp:126-127: 1 / pc with pc = pRR (depth limit) or 1 - pRR (the coin said stop). The quotient depends on
-                    // the material only and is formed on the host in the reference's order (stage.cpp), in both numerics modes.
+#if KAJO_STRICT
+                    L = L + T * (krcp(pc) * vE); // Shader.cpp:126-127
+#else
                     L = L + T * ((cont ? m.sDepth : m.sStop) * vE);
+#endif
                     pathDone = true;
                 } else {
                     float pt;
@@ -1112,7 +1255,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         float cosA = __builtin_fabsf(dot(nd, vN));
                         F3 spec = ld3(m.specular);
                         F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
-                        F3 w = (m.sTransparent * f) * __builtin_fabsf(dot(vN, nd)); // sTransparent = 1/pc * 1/pt, Shader.cpp:146-147
+#if KAJO_STRICT
+                        F3 w = (kdiv(krcp(pc) * 1.0f, pt) * f) * __builtin_fabsf(dot(vN, nd));
+#else
+                        F3 w = (m.sTransparent * f) * __builtin_fabsf(dot(vN, nd));
+#endif
                         L = L + T * (w * vE);
                         T = T * w;
                         O = vP + nd * kEps;
@@ -1125,7 +1272,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         vKind = diffuse ? 0 : (m.exponent != 0.0f ? 1 : 2);
                         vColor = diffuse ? ld3(m.diffuse) : ld3(m.specular);
                         vExp = m.exponent;
-                        vS = diffuse ? m.sDiffuse : m.sSpecular; // 1/pc * 1/pt * 1/pd, Shader.cpp:160-177
+#if KAJO_STRICT
+                        vS = kdiv(kdiv(krcp(pc) * 1.0f, pt) * 1.0f, pd); // 1/pc * 1/pt * 1/pd
+#else
+                        vS = diffuse ? m.sDiffuse : m.sSpecular;
+#endif
                         vR = reflect(view, vN);
                         vLd = f3(0.0f, 0.0f, 0.0f);
                         lightK = 0;
@@ -1288,9 +1439,12 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERN
     renderBody<false, false>(args, ldsRaw);
 }
 
-#ifdef KAJO_WITH_DEFERRED
-#include "deferred.inc.hip"
-#endif
+// large scenes, cooperative traversal: 8 waves pool and sort their rays every trip (see coopTrace)
+extern "C" __global__ void __launch_bounds__(512, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_COOP(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<false, false, false, true>(args, ldsRaw);
+}
 
 // known-answer kernels (kajo_hip_kat_shade / kajo_hip_kat_trace): the SAME device functions, fed rays
 extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KAT_SHADE_NAME(const RenderArgs args)

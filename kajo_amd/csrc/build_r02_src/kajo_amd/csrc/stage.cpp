@@ -1,0 +1,361 @@
+// stage.cpp -- host-side scene staging for the HIP backend.
+//
+// Does once per scene what cpu::Scene's constructor does (renderer/cpu/Scene.cpp:9-38:
+// invMatrix = glm::inverse(matrix), determinant = glm::determinant(matrix)) plus the camera
+// basis of renderer/cpu/Renderer.cpp:29-34 (three glm::unProject calls and inverse(view) *
+// (0,0,0,1)), and lays the result out as device_scene.h describes.
+//
+// The arithmetic follows glm 0.9.3.4's formulas in their operand order
+// (third_party/glm/glm/core/func_matrix.inl:446-580, gtc/matrix_transform.inl:337-356) in IEEE
+// binary32; this file must be compiled with FP contraction off (-ffp-contract=off), because the
+// STRICT kernels are compared bit for bit with a CPU evaluation of the same expressions.
+#include "stage.h"
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace kajo
+{
+
+namespace
+{
+
+// column-major 4x4, e(c, r) = element in column c, row r (glm's m[c][r])
+struct Mat4
+{
+    float v[16];
+    float e(int c, int r) const { return v[4 * c + r]; }
+    float& e(int c, int r) { return v[4 * c + r]; }
+};
+
+Mat4 load(const float* p)
+{
+    Mat4 m;
+    std::memcpy(m.v, p, sizeof m.v);
+    return m;
+}
+
+float det2(float a, float b, float c, float d) // a*b - c*d
+{
+    return a * b - c * d;
+}
+
+// cofactor expansion along the first column pair, func_matrix.inl:446-470
+float determinant(const Mat4& m)
+{
+    const float f00 = det2(m.e(2, 2), m.e(3, 3), m.e(3, 2), m.e(2, 3));
+    const float f01 = det2(m.e(2, 1), m.e(3, 3), m.e(3, 1), m.e(2, 3));
+    const float f02 = det2(m.e(2, 1), m.e(3, 2), m.e(3, 1), m.e(2, 2));
+    const float f03 = det2(m.e(2, 0), m.e(3, 3), m.e(3, 0), m.e(2, 3));
+    const float f04 = det2(m.e(2, 0), m.e(3, 2), m.e(3, 0), m.e(2, 2));
+    const float f05 = det2(m.e(2, 0), m.e(3, 1), m.e(3, 0), m.e(2, 1));
+    const float k0 = +(m.e(1, 1) * f00 - m.e(1, 2) * f01 + m.e(1, 3) * f02);
+    const float k1 = -(m.e(1, 0) * f00 - m.e(1, 2) * f03 + m.e(1, 3) * f04);
+    const float k2 = +(m.e(1, 0) * f01 - m.e(1, 1) * f03 + m.e(1, 3) * f05);
+    const float k3 = -(m.e(1, 0) * f02 - m.e(1, 1) * f04 + m.e(1, 2) * f05);
+    return m.e(0, 0) * k0 + m.e(0, 1) * k1 + m.e(0, 2) * k2 + m.e(0, 3) * k3;
+}
+
+// func_matrix.inl:523-580. The 18 two-by-two minors are indexed [pair of rows][pair of cols].
+Mat4 inverse(const Mat4& m)
+{
+    // minors of rows (2,3), (1,3), (1,2) over column pairs
+    float A[3], B[3], Cc[3], D[3], E[3], F[3];
+    const int ra[3] = {2, 1, 1}, rb[3] = {3, 3, 2};
+    for (int k = 0; k < 3; k++) {
+        const int p = ra[k], q = rb[k];
+        A[k] = det2(m.e(p, 2), m.e(q, 3), m.e(q, 2), m.e(p, 3));
+        B[k] = det2(m.e(p, 1), m.e(q, 3), m.e(q, 1), m.e(p, 3));
+        Cc[k] = det2(m.e(p, 1), m.e(q, 2), m.e(q, 1), m.e(p, 2));
+        D[k] = det2(m.e(p, 0), m.e(q, 3), m.e(q, 0), m.e(p, 3));
+        E[k] = det2(m.e(p, 0), m.e(q, 2), m.e(q, 0), m.e(p, 2));
+        F[k] = det2(m.e(p, 0), m.e(q, 1), m.e(q, 0), m.e(p, 1));
+    }
+    Mat4 r;
+    for (int i = 0; i < 4; i++) {
+        const int k = i < 2 ? 0 : i - 1;    // which row pair feeds result row i
+        const int c = i == 0 ? 1 : 0;       // source column of m for the weights
+        const float w0 = m.e(c, 0), w1 = m.e(c, 1), w2 = m.e(c, 2), w3 = m.e(c, 3);
+        const float sa = (i & 1) ? -1.f : +1.f;
+        const float sb = -sa;
+        r.e(0, i) = sa * (w1 * A[k] - w2 * B[k] + w3 * Cc[k]);
+        r.e(1, i) = sb * (w0 * A[k] - w2 * D[k] + w3 * E[k]);
+        r.e(2, i) = sa * (w0 * B[k] - w1 * D[k] + w3 * F[k]);
+        r.e(3, i) = sb * (w0 * Cc[k] - w1 * E[k] + w2 * F[k]);
+    }
+    const float det = m.e(0, 0) * r.e(0, 0) + m.e(0, 1) * r.e(1, 0) + m.e(0, 2) * r.e(2, 0) + m.e(0, 3) * r.e(3, 0);
+    for (float& x : r.v)
+        x = x / det;
+    return r;
+}
+
+// type_mat4x4.inl:757-779
+Mat4 multiply(const Mat4& a, const Mat4& b)
+{
+    Mat4 r;
+    for (int c = 0; c < 4; c++)
+        for (int i = 0; i < 4; i++)
+            r.e(c, i) = a.e(0, i) * b.e(c, 0) + a.e(1, i) * b.e(c, 1) + a.e(2, i) * b.e(c, 2) + a.e(3, i) * b.e(c, 3);
+    return r;
+}
+
+// type_mat4x4.inl:689-700
+void transform(const Mat4& a, const float in[4], float out[4])
+{
+    for (int i = 0; i < 4; i++)
+        out[i] = a.e(0, i) * in[0] + a.e(1, i) * in[1] + a.e(2, i) * in[2] + a.e(3, i) * in[3];
+}
+
+// gtc/matrix_transform.inl:337-356 with viewport (0, 0, 1, 1)
+void unProject(const Mat4& invPV, float wx, float wy, float wz, float out[3])
+{
+    float t[4] = {wx, wy, wz, 1.f};
+    t[0] = (t[0] - 0.f) / 1.f;
+    t[1] = (t[1] - 0.f) / 1.f;
+    for (float& c : t)
+        c = c * 2.f - 1.f;
+    float o[4];
+    transform(invPV, t, o);
+    for (int i = 0; i < 3; i++)
+        out[i] = o[i] / o[3];
+}
+
+bool isPureTranslation(const Mat4& m)
+{
+    for (int c = 0; c < 3; c++)
+        for (int r = 0; r < 4; r++)
+            if (m.e(c, r) != (c == r ? 1.f : 0.f))
+                return false;
+    return m.e(3, 3) == 1.f;
+}
+
+float max2(float a, float b) { return a < b ? b : a; } // glm::max / std::max
+
+DMaterial stageMaterial(const KajoMaterial& k)
+{
+    DMaterial d;
+    std::memset(&d, 0, sizeof d);
+    for (int i = 0; i < 3; i++) {
+        d.diffuse[i] = k.diffuse[i];
+        d.specular[i] = k.specular[i];
+        d.emission[i] = k.emission[i];
+        d.transparency[i] = k.transparency[i];
+    }
+    // Shader.cpp:124-125 + Random.cpp:104-109
+    float mx[3];
+    for (int i = 0; i < 3; i++)
+        mx[i] = max2(max2(k.diffuse[i], k.specular[i]), k.transparency[i]);
+    d.pRR = max2(mx[0], max2(mx[1], mx[2]));
+    // Shader.cpp:130-133,153
+    const float sd = k.diffuse[0] + k.diffuse[1] + k.diffuse[2];
+    const float ss = k.specular[0] + k.specular[1] + k.specular[2];
+    const float st = k.transparency[0] + k.transparency[1] + k.transparency[2];
+    d.pT = st / (sd + ss + st);
+    d.pD = sd / (sd + ss);
+    d.exponent = k.specularExponent;
+    d.ior = k.refractiveIndex;
+    d.isLight = !(k.emission[0] == 0 && k.emission[1] == 0 && k.emission[2] == 0 && k.emission[3] == 0);
+    d.sTransparent = 1.f / d.pRR * 1.f / d.pT;
+    d.sDiffuse = 1.f / d.pRR * 1.f / (1.f - d.pT) * 1.f / d.pD;
+    d.sSpecular = 1.f / d.pRR * 1.f / (1.f - d.pT) * 1.f / (1.f - d.pD);
+    d.sStop = 1.f / (1.f - d.pRR);
+    d.sDepth = 1.f / d.pRR;
+    return d;
+}
+
+// World-space bounding box of sphere i: the unit-radius-r sphere under M is an ellipsoid whose
+// half-extent along world axis k is r * |row k of mat3(M)|.
+void sphereBounds(const KajoSphere& sp, float lo[3], float hi[3])
+{
+    const Mat4 M = load(sp.transform);
+    for (int k = 0; k < 3; k++) {
+        const double e = (double)sp.radius * std::sqrt((double)M.e(0, k) * M.e(0, k) + (double)M.e(1, k) * M.e(1, k) +
+                                                        (double)M.e(2, k) * M.e(2, k));
+        const double c = M.e(3, k);
+        const double pad = 1e-4 * (e + std::fabs(c)) + 1e-5; // registration margin >> float rounding of the DDA
+        lo[k] = (float)(c - e - pad);
+        hi[k] = (float)(c + e + pad);
+    }
+}
+
+void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
+{
+    out.gridEnabled = false;
+    const int n = s.nSpheres;
+    if (n < gridMinSpheres || gridMinSpheres <= 0 || n > 65535) // (cell lists hold 16-bit sphere indices)
+        return;
+    // The walk compares the reported distances t * determinant (Raytracer.cpp:71,97) with WORLD-space cell
+    // boundaries, which is only sound when the two agree: every sphere determinant exactly 1 (t itself is the world-space
+    // ray parameter under any affine transform) and every plane rigid to within float rounding (far inside the
+    // registration margin below). A scaled sphere (det != 1) anywhere keeps the every-sphere walk.
+    if (!out.planesRigid)
+        return;
+    for (int i = 0; i < n; i++)
+        if (out.invDet[17 * ((size_t)s.nPlanes + i) + 16] != 1.f)
+            return;
+    std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
+    float bmin[3] = {3e38f, 3e38f, 3e38f}, bmax[3] = {-3e38f, -3e38f, -3e38f};
+    for (int i = 0; i < n; i++) {
+        sphereBounds(s.spheres[i], &lo[3 * i], &hi[3 * i]);
+        for (int k = 0; k < 3; k++) {
+            if (!(lo[3 * i + k] > -3e37f && hi[3 * i + k] < 3e37f))
+                return; // non-finite geometry: keep the brute-force walk
+            bmin[k] = std::fmin(bmin[k], lo[3 * i + k]);
+            bmax[k] = std::fmax(bmax[k], hi[3 * i + k]);
+        }
+    }
+    // about four cells per sphere, cells as cubic as the bounds allow, at most 128 per axis
+    double ext[3], vol = 1;
+    for (int k = 0; k < 3; k++) {
+        ext[k] = std::fmax((double)bmax[k] - bmin[k], 1e-3);
+        vol *= ext[k];
+    }
+    double cellsPerSphere = 1.0; // measured on the 1000-sphere scene: 0.5 .. 2 within 10 %, finer grids lose to the cell stepping
+    if (const char* e = std::getenv("KAJO_GRID_CELLS_PER_SPHERE")) // tuning knob
+        cellsPerSphere = std::atof(e) > 0 ? std::atof(e) : cellsPerSphere;
+    const double side = std::cbrt(vol / (cellsPerSphere * n));
+    size_t cells = 1;
+    for (int k = 0; k < 3; k++) {
+        int d = (int)std::ceil(ext[k] / side);
+        d = d < 1 ? 1 : (d > 128 ? 128 : d);
+        out.gridDim[k] = d;
+        out.gridMin[k] = bmin[k];
+        out.gridMax[k] = bmax[k];
+        out.gridCell[k] = (float)(ext[k] / d);
+        cells *= (size_t)d;
+    }
+    auto cellRange = [&](int i, int k, int& a, int& b) {
+        a = (int)std::floor((lo[3 * i + k] - bmin[k]) / out.gridCell[k]);
+        b = (int)std::floor((hi[3 * i + k] - bmin[k]) / out.gridCell[k]);
+        a = a < 0 ? 0 : (a >= out.gridDim[k] ? out.gridDim[k] - 1 : a);
+        b = b < 0 ? 0 : (b >= out.gridDim[k] ? out.gridDim[k] - 1 : b);
+    };
+    std::vector<uint32_t> count(cells + 1, 0);
+    for (int pass = 0; pass < 2; pass++) {
+        for (int i = 0; i < n; i++) { // ascending sphere index within every cell
+            int x0, x1, y0, y1, z0, z1;
+            cellRange(i, 0, x0, x1);
+            cellRange(i, 1, y0, y1);
+            cellRange(i, 2, z0, z1);
+            for (int z = z0; z <= z1; z++)
+                for (int y = y0; y <= y1; y++)
+                    for (int x = x0; x <= x1; x++) {
+                        const size_t c = ((size_t)z * out.gridDim[1] + y) * out.gridDim[0] + x;
+                        if (pass == 0)
+                            count[c + 1]++;
+                        else
+                            out.gridItems[count[c]++] = (uint16_t)i;
+                    }
+        }
+        if (pass == 0) {
+            for (size_t c = 0; c < cells; c++)
+                count[c + 1] += count[c];
+            out.gridCellStart = count;
+            out.gridItems.assign(count[cells], 0);
+        }
+    }
+    out.gridEnabled = true;
+}
+
+} // namespace
+
+void stageScene(const KajoScene& s, StagedScene& out, int gridMinSpheres)
+{
+    out = StagedScene();
+    out.nPlanes = s.nPlanes;
+    out.nSpheres = s.nSpheres;
+    for (int i = 0; i < 3; i++)
+        out.background[i] = s.backgroundColor[i];
+
+    for (int i = 0; i < s.nPlanes; i++) {
+        const Mat4 M = load(s.planes[i].transform);
+        const Mat4 inv = inverse(M);
+        const float det = determinant(M);
+        out.invDet.insert(out.invDet.end(), inv.v, inv.v + 16);
+        out.invDet.push_back(det);
+        out.planeRow.push_back(DFloat4{inv.e(0, 1), inv.e(1, 1), inv.e(2, 1), inv.e(3, 1)});
+        out.planeDet.push_back(det);
+        // FAST numerics drop the "* determinant" of Raytracer.cpp:97 when every plane is rigid to
+        // within float rounding of a rotation matrix (|det - 1| <= 2^-20; spheres.json: 0.9999997)
+        if (!(std::fabs(det - 1.f) <= 9.5367431640625e-7f))
+            out.planesRigid = 0;
+        // Raytracer.cpp:91-93: normal = mat3(M) * -(0,1,0); tangent = mat3(M) * (1,0,0); binormal = n x t
+        float n[3], t[3];
+        for (int r = 0; r < 3; r++) {
+            n[r] = M.e(0, r) * -0.f + M.e(1, r) * -1.f + M.e(2, r) * -0.f;
+            t[r] = M.e(0, r) * 1.f + M.e(1, r) * 0.f + M.e(2, r) * 0.f;
+        }
+        const float b[3] = {n[1] * t[2] - t[1] * n[2], n[2] * t[0] - t[2] * n[0], n[0] * t[1] - t[0] * n[1]};
+        out.planeFrame.push_back(DFloat4{n[0], n[1], n[2], 0.f});
+        out.planeFrame.push_back(DFloat4{t[0], t[1], t[2], 0.f});
+        out.planeFrame.push_back(DFloat4{b[0], b[1], b[2], 0.f});
+        out.material.push_back(stageMaterial(s.planes[i].material));
+    }
+
+    out.allTranslated = 1;
+    for (int i = 0; i < s.nSpheres; i++) {
+        const Mat4 M = load(s.spheres[i].transform);
+        const Mat4 inv = inverse(M);
+        const float det = determinant(M);
+        out.invDet.insert(out.invDet.end(), inv.v, inv.v + 16);
+        out.invDet.push_back(det);
+        const float radius = s.spheres[i].radius;
+        const float r2 = radius * radius;
+        const float zero[4] = {0.f, 0.f, 0.f, 1.f};
+        float c[4];
+        transform(M, zero, c); // Light.cpp:37
+        DSphereCold cold;
+        std::memset(&cold, 0, sizeof cold);
+        cold.cx = c[0];
+        cold.cy = c[1];
+        cold.cz = c[2];
+        cold.radius = radius;
+        for (int r = 0; r < 3; r++)
+            for (int k = 0; k < 3; k++)
+                cold.m[3 * r + k] = M.e(k, r);
+        const bool translated = isPureTranslation(M) && det == 1.f && isPureTranslation(inv);
+        cold.general = !translated;
+        cold.invRadius = 1.f / radius;
+        cold.invTwoPiR2 = 1.f / (6.28318530717958647692f * r2);
+        uint32_t off = (uint32_t)out.sphereHot.size();
+        if (translated) {
+            // inverse is translate(-c) exactly: object-space origin = O + inv[3] = O - c
+            out.sphereHot.push_back(DFloat4{inv.e(3, 0), inv.e(3, 1), inv.e(3, 2), r2});
+        } else {
+            out.allTranslated = 0;
+            off |= KAJO_SPHERE_GENERAL;
+            for (int r = 0; r < 3; r++)
+                out.sphereHot.push_back(DFloat4{inv.e(0, r), inv.e(1, r), inv.e(2, r), inv.e(3, r)});
+            out.sphereHot.push_back(DFloat4{r2, det, 0.f, 0.f});
+        }
+        out.sphereHotOffset.push_back(off);
+        out.sphereCold.push_back(cold);
+        DMaterial m = stageMaterial(s.spheres[i].material);
+        out.material.push_back(m);
+        if (m.isLight)
+            out.light.push_back(i);
+    }
+
+    buildGrid(s, out, gridMinSpheres);
+
+    // camera basis, Renderer.cpp:29-34
+    const Mat4 view = load(s.camera.transform);
+    const Mat4 proj = load(s.camera.projection);
+    const Mat4 invPV = inverse(multiply(proj, view));
+    float p1[3], p2[3], p3[3];
+    unProject(invPV, 0.f, 0.f, 0.f, p1);
+    unProject(invPV, 1.f, 0.f, 0.f, p2);
+    unProject(invPV, 0.f, 1.f, 0.f, p3);
+    const float zero[4] = {0.f, 0.f, 0.f, 1.f};
+    float o[4];
+    transform(inverse(view), zero, o);
+    for (int i = 0; i < 3; i++) {
+        out.p1[i] = p1[i];
+        out.p2[i] = p2[i];
+        out.p3[i] = p3[i];
+        out.origin[i] = o[i];
+    }
+}
+
+} // namespace kajo

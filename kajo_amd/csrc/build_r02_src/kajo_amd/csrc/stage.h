@@ -1,0 +1,39 @@
+// stage.h -- host image of the render-ready scene (see device_scene.h for the layout).
+#ifndef KAJO_STAGE_H
+#define KAJO_STAGE_H
+
+#include <vector>
+
+#include "device_scene.h"
+#include "kajo_scene.h"
+
+namespace kajo
+{
+
+struct StagedScene
+{
+    int nPlanes = 0, nSpheres = 0, allTranslated = 1, planesRigid = 1;
+    float background[3] = {0, 0, 0};
+    float p1[3], p2[3], p3[3], origin[3]; // Renderer.cpp:30-34
+    std::vector<DFloat4> planeRow;
+    std::vector<float> planeDet;
+    std::vector<DFloat4> planeFrame;
+    std::vector<DFloat4> sphereHot;
+    std::vector<uint32_t> sphereHotOffset;
+    std::vector<DSphereCold> sphereCold;
+    std::vector<DMaterial> material;
+    std::vector<int32_t> light;
+    std::vector<float> invDet; // 17 floats per object, planes first (debug / tests)
+    // uniform grid over the spheres (built when there are at least `gridMinSpheres` of them)
+    bool gridEnabled = false;
+    int gridDim[3] = {0, 0, 0};
+    float gridMin[3], gridMax[3], gridCell[3];
+    std::vector<uint32_t> gridCellStart;
+    std::vector<uint16_t> gridItems;
+};
+
+void stageScene(const KajoScene& scene, StagedScene& out, int gridMinSpheres = 48);
+
+} // namespace kajo
+
+#endif

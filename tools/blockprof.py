@@ -5,6 +5,8 @@ import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("KAJO_HIP_LIB", os.path.join(ROOT, "kajo_amd", "libkajo_hip_prof.so"))
+if not os.path.exists(os.environ["KAJO_HIP_LIB"]):
+    sys.exit("blockprof: %s missing -- build it first: make -C kajo_amd/csrc prof" % os.environ["KAJO_HIP_LIB"])
 import numpy as np, warnings
 warnings.filterwarnings('ignore')
 from kajo_amd.renderer import HipRenderer
@@ -23,7 +25,7 @@ with HipRenderer(sc, W, H, counters=True, strict=(mode == 'strict')) as r:
     out = (C.c_ulonglong * 28)()
     capi.check(capi.lib().kajo_hip_debug_profile(r._h, out))
 iters = c['laneSlots'] / 64
-names = ['NEW', 'pend-weight', 'vertex', 'transparent', 'lobe-select', 'light/BSDF entry', 'shadow-result', 'BSDF-sample']
+names = ['camera (issue)', 'resume parked vertex', 'shadow ray generated', 'BSDF-sample', 'vertex', 'transparent', 'park (push)', 'shadow-result']
 print('%s %s %dx%d x%d: wave-iterations %.3e, paths %.3e, kernel ms %.2f, trav/path %.3f, vert/path %.3f' % (
     mode, which, W, H, passes, iters, c['paths'], c['kernelMs'], c['traversals'] / c['paths'], c['vertices'] / c['paths']))
 for k, n in enumerate(names):
@@ -31,5 +33,5 @@ for k, n in enumerate(names):
     print('%-18s executed in %5.1f%% of iterations, %4.1f lanes active when executed (%.0f%%)' % (n, 100 * ex / iters, la / max(ex, 1), 100 * la / max(ex, 1) / 64))
 st = [out[16 + k] for k in range(5)]
 tot = sum(st)
-for n, v in zip(['camera-ray block', 'traversal', 'vertex/shadow-result block', 'light+BSDF block', 'tail/back-edge'], st):
+for n, v in zip(['camera-ray block (before the ray)', 'light+BSDF block (before the ray)', 'traversal', 'vertex/shadow-result block', 'retire/back-edge'], st):
     print('%-28s %5.1f%% of wave time, %.0f cycles per iteration' % (n, 100 * v / tot, v / iters))

@@ -653,19 +653,19 @@ KDEV void renderBodyDeferred(const RenderArgs& args, unsigned char* ldsRaw)
 
 } // namespace
 
-extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_DEFERRED(const RenderArgs args)
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KERNEL_NAME_DEFERRED(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBodyDeferred<true, false>(args, ldsRaw);
 }
 
-extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_DEFERRED_BIG(const RenderArgs args)
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KERNEL_NAME_DEFERRED_BIG(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBodyDeferred<false, false>(args, ldsRaw);
 }
 
-extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KAT_SHADE_NAME_DEFERRED(const RenderArgs args)
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KAT_SHADE_NAME_DEFERRED(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBodyDeferred<false, true>(args, ldsRaw);

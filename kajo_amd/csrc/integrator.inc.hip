@@ -711,8 +711,14 @@ enum : int
 
 } // namespace
 
+// Register budgets (launch bounds). Throughput follows the number of resident waves almost linearly (profiles/r03_deferred_experiment.txt,
+// sweep 3: 2 / 3 / 4 waves per SIMD -> 23.3 / 29.7 / 38.5 G paths/s), so the FAST loop is kept within 96 VGPRs = 5 waves per SIMD
+// (kernel_fast.hip); STRICT and the large-scene kernels need 128.
 #ifndef KAJO_WAVES_PER_SIMD
-#define KAJO_WAVES_PER_SIMD 4 // register budget: 512 / 4 = 128 VGPRs per lane
+#define KAJO_WAVES_PER_SIMD 4 // 512 / 4 = 128 VGPRs per lane
+#endif
+#ifndef KAJO_WAVES_PER_SIMD_BIG
+#define KAJO_WAVES_PER_SIMD_BIG 4
 #endif
 
 namespace
@@ -829,22 +835,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     const bool inImage = KAT ? (int)slot < args.katCount : (ownedTile < args.nTilesOwned && px < args.W && py < args.H);
 
     const int n = args.n;
-    const uint32_t pixelIndex = (uint32_t)(py * args.W + px);
     // include/kajo_stream.h: key words (pixel, sample | pass << 16, seed lo ^ pass >> 16, seed hi) ^ constants
-    const uint32_t keyA = pixelIndex ^ 0x61707865u;
     const uint32_t keyC = (uint32_t)args.seed ^ 0x79622d32u;
     const uint32_t keyD = (uint32_t)(args.seed >> 32) ^ 0x6b206574u;
+    // first pixel of the wave's 8x8 block: the pixel of lane l is (blockX + (l & 7), blockY + (l >> 3))
+    const int blockX = __builtin_amdgcn_readfirstlane(px - (lane & 7)), blockY = __builtin_amdgcn_readfirstlane(py - (lane >> 3));
 
     const F3 p1 = ld3(sc.p1), dp2 = ld3(sc.dp2), dp3 = ld3(sc.dp3), origin = ld3(sc.origin);
     const F3 background = ld3(sc.background);
-    // x * pixelWidth and (H - y) * pixelHeight of Renderer.cpp:56-57 are constants of the pixel
-    const float pixX = px * args.pixelWidth;
-    const float pixY = (args.H - py) * args.pixelHeight;
-    // The pixel whose pass the lane is rendering right now: its own, or -- near the end of the wave's
-    // life -- one taken over from a lane that still has whole passes left (see "pass stealing" below).
-    uint32_t curKeyA = keyA;
-    float curPixX = pixX, curPixY = pixY;
-
     // accumulated radiance of the pixel (Renderer.cpp:70-71), continued across launches
     // (the handle zeroes the buffer when it is created or reset)
     F3 total = f3(0.0f, 0.0f, 0.0f);
@@ -880,14 +878,24 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     int depth = 0;
     bool collectEmission = true;
     // vertex being shaded
-    F3 vP = origin, vN = d, vR = d, vE = L, vLd = L, vColor = L;
+    // (the BSDF's colour, exponent and path-weight scale are constants of the material and the lobe: re-read where they are
+    // used instead of carried across the traversal. FAST also sums the vertex's emission and its light samples in one vector.)
+    F3 vP = origin, vN = d, vR = d, vE = L;
     int vId = 0, vKind = 0, lightK = 0;
-    float vExp = 0.0f, vS = 0.0f;
+#if KAJO_STRICT
+    F3 vLd = L;
+    float vS = 0.0f; // of the vertex the extension ray left: the MIS correction re-forms the weight with it
+#endif
     F3 pendContrib = L; // light sample's contribution if its shadow ray reaches the light
     // extension ray sampled from the BSDF: weight pieces that wait for the light pdf of the hit
     bool pendBsdf = false;
+    // (STRICT re-forms the weight from its pieces, in the reference's order; FAST scales the eager throughput by
+    // p / (pL + p) -- the same value -- and carries only p: seven registers less across the traversal)
+#if KAJO_STRICT
     F3 pendF = L, pendT = L;
-    float pendCos = 0.0f, pendP = 0.0f;
+    float pendCos = 0.0f;
+#endif
+    float pendP = 0.0f;
 
     unsigned long long ctrTraversals = 0, ctrVertices = 0, ctrSlots = 0;
     const bool counting = args.counters != nullptr;
@@ -973,9 +981,6 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 radiance = f3(0.0f, 0.0f, 0.0f);
                 sampleY = 0;
                 pass = ownPass;
-                curKeyA = keyA;
-                curPixX = pixX;
-                curPixY = pixY;
             }
             // out of own passes: take one over, or retire when nobody has one to give
             unsigned long long idleMask = __ballot(stolenFrom < 0 && ownPass >= myEnd);
@@ -990,22 +995,22 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // lowest idle lane takes the last pass of the lowest giver
                 const int thief = __builtin_ctzll(idleMask), giver = __builtin_ctzll(giverMask);
                 const int takenPass = __builtin_amdgcn_readlane(myEnd, giver) - 1;
-                const uint32_t gKey = (uint32_t)__builtin_amdgcn_readlane((int)keyA, giver);
-                const float gX = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pixX), giver));
-                const float gY = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pixY), giver));
                 if (lane == giver)
                     myEnd = takenPass;
                 if (lane == thief) {
                     stolenFrom = giver;
                     pass = takenPass;
-                    curKeyA = gKey;
-                    curPixX = gX;
-                    curPixY = gY;
                 }
                 idleMask &= idleMask - 1; // next idle lane
             }
             if (mode == MODE_NEW && (stolenFrom >= 0 || ownPass < myEnd)) {
-                uint32_t a = curKeyA, c = keyC ^ ((uint32_t)pass >> 16), dd = keyD;
+                // The pixel whose pass the lane is rendering: its own, or the one of the lane it took the pass over from (same
+                // 8x8 block). Its stream key word and x * pixelWidth, (H - y) * pixelHeight of Renderer.cpp:56-57 are formed here
+                // rather than carried in six registers through the whole loop.
+                const int srcLane = stolenFrom >= 0 ? stolenFrom : lane;
+                const int spx = blockX + (srcLane & 7), spy = blockY + (srcLane >> 3);
+                const float curPixX = spx * args.pixelWidth, curPixY = (args.H - spy) * args.pixelHeight;
+                uint32_t a = (uint32_t)(spy * args.W + spx) ^ 0x61707865u, c = keyC ^ ((uint32_t)pass >> 16), dd = keyD;
                 uint32_t b = ((uint32_t)(sampleY * n + sampleX) | ((uint32_t)pass << 16)) ^ 0x3320646eu;
                 KAJO_QUARTER_ROUND(a, b, c, dd);
                 KAJO_QUARTER_ROUND(a, b, c, dd);
@@ -1077,8 +1082,12 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #else
                     const float pL = lightPdf(lc, vP);
 #endif
+#if KAJO_STRICT
                     const F3 wb = (krcp(pL + pendP) * pendF) * pendCos;
                     T = pendT * (vS * wb);
+#else
+                    T = T * (pendP * krcp(pL + pendP));
+#endif
                 }
                 collectEmission = false; // SampleNonEmissiveObjects
                 pendBsdf = false;
@@ -1123,11 +1132,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         float pd;
                         const bool diffuse = flipCoin(rng, m.pD, pd); // Shader.cpp:153-154
                         vKind = diffuse ? 0 : (m.exponent != 0.0f ? 1 : 2);
-                        vColor = diffuse ? ld3(m.diffuse) : ld3(m.specular);
-                        vExp = m.exponent;
-                        vS = diffuse ? m.sDiffuse : m.sSpecular; // 1/pc * 1/pt * 1/pd, Shader.cpp:160-177
                         vR = reflect(view, vN);
+#if KAJO_STRICT
                         vLd = f3(0.0f, 0.0f, 0.0f);
+#endif
                         lightK = 0;
                         sampleNext = true;
                     }
@@ -1135,8 +1143,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             }
         } else if (mode == MODE_SHADOW) {
             // Shader.cpp:72-73: the sample counts iff the closest hit of the shadow ray IS the light
-            if (hit.id == np + 1 + lds.light[lightK])
+            if (hit.id == np + 1 + lds.light[lightK]) {
+#if KAJO_STRICT
                 vLd = vLd + pendContrib;
+#else
+                vE = vE + pendContrib;
+#endif
+            }
             lightK++;
             sampleNext = true;
         }
@@ -1144,6 +1157,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         KAJO_STAMP(2); // vertex / shadow-result block
         KAJO_PROF(5, sampleNext);
         if (sampleNext) {
+            const DMaterial& vm = lds.material[vId - 1];
+            const F3 vColor = vKind == 0 ? ld3(vm.diffuse) : ld3(vm.specular);
+            const float vExp = vm.exponent;
+            const float vSl = vKind == 0 ? vm.sDiffuse : vm.sSpecular; // 1/pc * 1/pt * 1/pd, Shader.cpp:160-177
             // ---- sampleLights (Shader.cpp:50-86), one light per trip ------------------------------
             bool shadowRay = false;
             while (lightK < sc.nLights) {
@@ -1195,15 +1212,24 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 float p;
                 F3 fd;
                 d = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
-                L = L + T * (vS * (vE + vLd));
+#if KAJO_STRICT
+                L = L + T * (vSl * (vE + vLd));
+                vS = vSl;
+#else
+                L = L + T * (vSl * vE);
+#endif
                 // The next segment's state is written unconditionally: a path that ends here (p == 0) re-initialises
                 // all of it when its lane starts the next camera path, and unconditional writes need no copies.
-                pendF = fd;
-                pendCos = kmax0(dot(vN, d));
                 pendP = p;
                 pendBsdf = true;
+#if KAJO_STRICT
+                pendF = fd;
+                pendCos = kmax0(dot(vN, d));
                 pendT = T;
-                T = T * (vS * ((krcp(0.0f + p) * pendF) * pendCos));
+                T = T * (vSl * ((krcp(0.0f + p) * pendF) * pendCos));
+#else
+                T = T * (vSl * ((krcp(p) * fd) * kmax0(dot(vN, d))));
+#endif
                 O = vP + d * kEps;
                 depth++;
                 if (p == 0.0f)
@@ -1282,7 +1308,7 @@ extern "C" __global__ void __launch_bounds__(1024, KAJO_WAVES_PER_SIMD) KAJO_KER
 }
 
 // hot records in LDS, cold ones in global memory (large scenes)
-extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_BIG(const RenderArgs args)
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KERNEL_NAME_BIG(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBody<false, false>(args, ldsRaw);
@@ -1293,7 +1319,7 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERN
 #endif
 
 // known-answer kernels (kajo_hip_kat_shade / kajo_hip_kat_trace): the SAME device functions, fed rays
-extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KAT_SHADE_NAME(const RenderArgs args)
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KAT_SHADE_NAME(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBody<false, true>(args, ldsRaw);

@@ -1,5 +1,8 @@
 // FAST numerics: the product path. Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast
 #define KAJO_STRICT 0
+#ifndef KAJO_WAVES_PER_SIMD
+#define KAJO_WAVES_PER_SIMD 5 // the FAST loop fits 96 VGPRs without spills (tools/vgpr_check.sh)
+#endif
 #define KAJO_KERNEL_NAME kajo_render_fast
 #define KAJO_KERNEL_NAME_BIG kajo_render_fast_big
 #define KAJO_KERNEL_NAME_SPLIT kajo_render_fast_split

@@ -51,7 +51,20 @@ WORKLOADS = {
     "c2": (1920, 1080, 16, 16, "BASELINE configs[1]"),
     "c3": (3840, 2160, 64, 64, "BASELINE configs[2]"),
 }
-PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r02_counters.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc runs
+PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r03_counters.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc runs
+KERNEL_SOURCES = ["kajo_amd/csrc/integrator.inc.hip", "kajo_amd/csrc/kernel_fast.hip", "kajo_amd/csrc/kernel_strict.hip",
+                  "kajo_amd/csrc/launch.inc.hip", "kajo_amd/csrc/render_args.h", "kajo_amd/csrc/device_scene.h",
+                  "kajo_amd/csrc/Makefile", "include/kajo_stream.h", "include/kajo_strictmath.h"]
+
+
+def kernel_source_hash():
+    """Identifies the kernels a counters file was collected on: SHA-256 over the sources the render kernels are built from."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
 
 
 class DevicePtr:
@@ -95,6 +108,8 @@ def profile_counters(kernel, workload):
     e = d.get(kernel)
     if not e or e.get("workload") != workload:
         return None
+    if e.get("kernel_source_hash") != kernel_source_hash():
+        return None  # collected on other kernels than the ones being timed: stale figures are not reported
     e = dict(e)
     e["source"] = os.path.relpath(PROFILE_COUNTERS, ROOT)
     return e
@@ -165,8 +180,9 @@ def parity_leg(scene, make_renderer, strict, passes):
             "px_off_by_more_than_1e-3": int((np.abs(cl).max(-1) > 1e-3).sum()), "nonfinite_px": int((~m).any(-1).sum())}
 
 
-def other_mode_leg(scene, W, H, passes, ppl, local_rank, strict):
-    """The kernels of the numerics mode that was NOT timed, on the same frame: rate and parity."""
+def other_mode_leg(scene, W, H, passes, ppl, local_rank, strict, fpp):
+    """The kernels of the numerics mode that was NOT timed, on the same frame: rate, roofline fraction (the same algorithmic
+    FLOP per path: both modes trace the same paths) and parity."""
     from kajo_amd.renderer import HipRenderer
 
     def mk(w, h):
@@ -180,9 +196,12 @@ def other_mode_leg(scene, W, H, passes, ppl, local_rank, strict):
     dt = time.perf_counter() - t0
     c1 = r.counters()
     r.close()
+    kernel_ms = (c1["kernelMs"] - c0["kernelMs"]) / max(c1["launches"] - c0["launches"], 1)
+    achieved = fpp * (c1["paths"] - c0["paths"]) / max(c1["launches"] - c0["launches"], 1) / (kernel_ms * 1e-3) / 1e12
     return {"numerics": "strict" if strict else "fast", "value": (c1["paths"] - c0["paths"]) / dt / 1e6, "unit": "Msamples/s",
-            "ms_per_step": dt * 1e3,
-            "kernel_ms_per_launch": (c1["kernelMs"] - c0["kernelMs"]) / max(c1["launches"] - c0["launches"], 1),
+            "ms_per_step": dt * 1e3, "kernel_ms_per_launch": kernel_ms,
+            "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
+                         "kernel": "kajo_render_strict" if strict else "kajo_render_fast", "flops_per_path": fpp},
             "parity": parity_leg(scene, mk, strict, passes)}
 
 
@@ -377,7 +396,8 @@ def main():
         roof = {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "traffic": pc["hbm_bytes_per_launch"] if pc else None,
-                "traffic_source": (pc["source"] + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, round 2, this command)") if pc else None,
+                "traffic_source": (pc["source"] + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over this command, on kernels with this source hash)") if pc
+                                  else "no counters file for these kernels (tools/profile_round.sh rewrites profiles/r03_counters.json)",
                 "kernel": kernel, "kernel_ms_per_launch": kernel_ms, "launches_per_step": launches / args.steps,
                 "passes_per_launch": ppl,
                 "flops_per_path": fpp, "traversals_per_path": trav, "vertices_per_path": vert,
@@ -392,12 +412,15 @@ def main():
         out = {
             "metric": "Msamples/s", "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong" if world > 1 else "weak",
+            "scaling": "strong" if world > 1 else None,  # one GPU: nothing scales
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": workload, "numerics": "strict" if strict else "fast",
                        "tiles": "64x16 round-robin over ranks", "paths_per_step": paths_per_step,
                        "world_size_seen_by_backend": (dist.get_world_size() if world > 1 else 1),
-                       "backend": (args.backend if world > 1 else None)},
+                       "backend": (args.backend if world > 1 else None),
+                       # which library was timed (KAJO_HIP_LIB can point the binding at a diagnostic twin; never a CPU path)
+                       "library": os.path.relpath(capi.LIB_PATH, ROOT), "library_version": capi.lib().kajo_hip_version().decode(),
+                       "kernel_source_hash": kernel_source_hash()},
             "roofline": roof,
             "in_kernel_value": paths_per_launch / (kernel_ms * 1e-3) / 1e6 * world,
             "mtraversals_per_s": value * trav,
@@ -414,15 +437,27 @@ def main():
                 out["multi_gpu"].update(check)
     r.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the parity legs first, the timed CPU baseline last (its libraries are built with the reference's fast-math flags)
+        out["parity"] = parity_leg(scene, factory, strict, PASSES)
+        other = other_mode_leg(scene, W, H, PASSES, ppl, local_rank, not strict, out["roofline"]["flops_per_path"])
         out["cpu_baseline"] = cpu_baseline(scene, W, H)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
-        out["parity"] = parity_leg(scene, factory, strict, PASSES)
-        other = other_mode_leg(scene, W, H, PASSES, ppl, local_rank, not strict)
         other["speedup_vs_cpu_baseline"] = other["value"] / out["cpu_baseline"]["value"]
         out["strict_mode" if not strict else "fast_mode"] = other
-        meets = [m for m, p in (("strict" if strict else "fast", out["parity"]), (other["numerics"], other["parity"]))
-                 if p["meets_north_star_rmse"]]
-        out["modes_meeting_north_star_rmse_1e-4"] = meets
+        timed = {"numerics": "strict" if strict else "fast", "value": out["value"], "ms_per_step": out["ms_per_step"],
+                 "roofline": out["roofline"], "parity": out["parity"], "speedup_vs_cpu_baseline": out["speedup_vs_cpu_baseline"]}
+        meeting = [m for m in (timed, other) if m["parity"]["meets_north_star_rmse"]]
+        out["modes_meeting_north_star_rmse_1e-4"] = [m["numerics"] for m in meeting]
+        # BASELINE.json's two targets at once (>= 100 x the CPU backend AND per-pixel RMSE < 1e-4): the fastest mode whose parity
+        # leg meets the RMSE figure, as a number of its own. `value` stays the FAST rate (inside SURVEY section 8c's tolerance).
+        if meeting:
+            best = max(meeting, key=lambda m: m["value"])
+            out["north_star_mode"] = {"numerics": best["numerics"], "value": best["value"], "unit": "Msamples/s",
+                                      "ms_per_step": best["ms_per_step"], "roofline_frac": best["roofline"]["frac"],
+                                      "rmse": best["parity"]["rmse_clamped01"], "bit_identical_px": best["parity"]["bit_identical_px"],
+                                      "px": best["parity"]["px"], "speedup_vs_cpu_baseline": best["speedup_vs_cpu_baseline"]}
+        else:
+            out["north_star_mode"] = None
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

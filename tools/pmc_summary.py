@@ -33,4 +33,14 @@ for k in sorted(agg):
     for key in ('hbm_bytes_per_launch', 'valu_lane_utilisation', 'executed_fp32_flops_per_launch', 'salu_per_valu'):
         if key in d: print('  => %-29s %.6g' % (key, d[key]))
     res[k.split('(')[0]] = d
+# the kernels these figures belong to: bench.py reports them only while the sources still hash to this value
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_for_hash', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py'))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    for d in res.values():
+        d['kernel_source_hash'] = b.kernel_source_hash()
+except Exception as e:
+    print('no source hash:', e)
 json.dump(res, open(os.path.join(out, 'counters.json'), 'w'), indent=1, sort_keys=True)

@@ -367,7 +367,7 @@ KDEV void renderBodyDeferred(const RenderArgs& args, unsigned char* ldsRaw)
                     lightK++;
                     continue;
                 }
-                const DSphereCold& lc = lds.sphereCold[si];
+                const DSphereCold& lc = lds.lightCold[lightK];
                 float pl;
                 // written straight into the ray: a discarded sample leaves d and O to the next light or to the BSDF sample
                 d = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
@@ -388,7 +388,8 @@ KDEV void renderBodyDeferred(const RenderArgs& args, unsigned char* ldsRaw)
                     lightK++;
                     continue;
                 }
-                const F3 Le = ld3(lds.material[np + si].emission);
+                const DFloat4 le = lds.lightEmission[lightK];
+                const F3 Le = f3(le.x, le.y, le.z);
                 pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
                 lightObj = np + 1 + si;
                 shadowRay = true;

@@ -169,7 +169,9 @@ struct LdsScene
     const DFloat4* planeFrame;
     const DSphereCold* sphereCold;
     const DMaterial* material;
-    const int32_t* light;
+    const int32_t* light;          // [nLights] sphere indices, always in LDS
+    const DSphereCold* lightCold;  // [nLights] the lights' own cold records and
+    const DFloat4* lightEmission;  // [nLights] emissions, always in LDS: a large scene's light loop reads nothing from global memory
     const uint32_t* gridCellStart; // LDS copy when it fits (DGrid.inLds), else the global arrays
     const uint16_t* gridItems;
 };
@@ -474,10 +476,11 @@ KDEV F3 hitNormal(const DSceneView& sc, const LdsScene& lds, const Hit& h, F3 O,
         F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
         return normalize(o + d * h.t0); // mat3(M) = identity
 #else
-        // the hit point minus the centre has length r: scale instead of normalising
-        const DSphereCold& sc_ = lds.sphereCold[si];
-        F3 o = f3(O.x - sc_.cx, O.y - sc_.cy, O.z - sc_.cz);
-        return (o + d * h.t0) * sc_.invRadius;
+        // the hit point minus the centre has length r: scale instead of normalising; (-centre, r^2) is the hot record
+        // itself (in LDS for every scene size), 1 / r its reciprocal square root
+        const DFloat4 s = lds.sphereHot[off];
+        F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+        return (o + d * h.t0) * krsq(s.w);
 #endif
     }
     const int k = (int)(off & ~KAJO_SPHERE_GENERAL);
@@ -740,7 +743,8 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
 {
     const int np = sc.nPlanes, ns = sc.nSpheres;
     // layout: [planeRow np x16][sphereHot nHot x16]{[planeFrame 3np x16][sphereCold ns x64]
-    //         [material (np+ns) x96]}[planeDet np x4][sphereHotOffset ns x4]{[light nL x4]}
+    //         [material (np+ns) x96]}[planeDet np x4][sphereHotOffset ns x4][light nL x4] (pad to 16)
+    //         [lightCold nL x64][lightEmission nL x16]{[grid cell starts][grid items]}
     DFloat4* ldsPlaneRow = reinterpret_cast<DFloat4*>(ldsRaw);
     DFloat4* ldsSphereHot = ldsPlaneRow + np;
     DFloat4* cursor = ldsSphereHot + sc.nSphereHot;
@@ -772,17 +776,28 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
         ldsPlaneDet[i] = sc.planeDet[i];
     for (int i = threadIdx.x; i < ns; i += blockDim.x)
         ldsSphereOff[i] = sc.sphereHotOffset[i];
-    if (COLD_LDS)
-        for (int i = threadIdx.x; i < sc.nLights; i += blockDim.x)
-            ldsLight[i] = sc.light[i];
+    for (int i = threadIdx.x; i < sc.nLights; i += blockDim.x)
+        ldsLight[i] = sc.light[i];
     lds.planeDet = ldsPlaneDet;
     lds.sphereHotOffset = ldsSphereOff;
-    lds.light = COLD_LDS ? ldsLight : sc.light;
+    lds.light = ldsLight;
+    // the lights' records, by light index: [lightCold nL x64][lightEmission nL x16], 16-byte aligned behind the 4-byte arrays
+    const uintptr_t words = (uintptr_t)(np + ns + sc.nLights);
+    DFloat4* lc4 = reinterpret_cast<DFloat4*>(ldsPlaneDet + ((words + 3u) & ~(uintptr_t)3u));
+    DFloat4* le4 = lc4 + 4 * sc.nLights;
+    for (int i = threadIdx.x; i < 4 * sc.nLights; i += blockDim.x)
+        lc4[i] = reinterpret_cast<const DFloat4*>(sc.sphereCold + sc.light[i >> 2])[i & 3];
+    for (int i = threadIdx.x; i < sc.nLights; i += blockDim.x) {
+        const DMaterial& lm = sc.material[np + sc.light[i]];
+        le4[i] = DFloat4{lm.emission[0], lm.emission[1], lm.emission[2], 0.0f};
+    }
+    lds.lightCold = reinterpret_cast<const DSphereCold*>(lc4);
+    lds.lightEmission = le4;
     lds.gridCellStart = sc.grid.cellStart;
     lds.gridItems = sc.grid.items;
     if (!COLD_LDS && sc.grid.enabled && sc.grid.inLds) {
         // the DDA reads two cell offsets per step: from LDS that is ~64 cycles, from L2 ~500
-        uint32_t* cs = reinterpret_cast<uint32_t*>(ldsSphereOff + ns);
+        uint32_t* cs = reinterpret_cast<uint32_t*>(le4 + sc.nLights);
         uint16_t* it = reinterpret_cast<uint16_t*>(cs + sc.grid.nCells + 1);
         for (int i = threadIdx.x; i <= sc.grid.nCells; i += blockDim.x)
             cs[i] = sc.grid.cellStart[i];
@@ -1169,7 +1184,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     lightK++;
                     continue;
                 }
-                const DSphereCold& lc = lds.sphereCold[si];
+                const DSphereCold& lc = lds.lightCold[lightK];
                 float pl;
                 // written straight into the ray: a discarded sample leaves d and O to the next light or to the BSDF sample
                 d = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
@@ -1190,7 +1205,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     lightK++;
                     continue;
                 }
-                const F3 Le = ld3(lds.material[np + si].emission);
+                const DFloat4 le = lds.lightEmission[lightK];
+                const F3 Le = f3(le.x, le.y, le.z);
                 pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
                 mode = MODE_SHADOW;
                 shadowRay = true;

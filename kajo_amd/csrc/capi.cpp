@@ -605,8 +605,41 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         }
         while (split > 1 && a.mailboxOffset + (size_t)now * 64 * 16 + split * h->perWaveBytes(false) > 48 * 1024)
             split /= 2; // the table and the waves' areas would need the large-LDS opt-in: not worth it
+        // Launches of FEW passes (BASELINE configs[0] is one pass of 16 samples on 1024 pixel blocks: a quarter of the chip's SIMDs,
+        // one wave each): the waves of a block divide the SAMPLES of every pass instead -- `chunks` per pass, now * chunks waves
+        // per block -- and the paths' radiances meet in the table [pass][sample][pixel]. Chosen when it puts more waves on a
+        // block than dividing the passes does.
+        unsigned chunks = 1;
+        if (h->coldInLds && !(p.flags & KAJO_FLAG_NO_SPLIT) && !h->deferred && pixelBlocks < 3 * 4096) {
+            const unsigned nn = (unsigned)(a.n * a.n);
+            // the smallest division that gives the launch one round of the chip's wave slots (measured on configs[0], 1024 blocks:
+            // 4 chunks 18.0, 8 chunks 17.4, 16 chunks 15.5 G paths/s against 8.3 undivided; profiles/r03_configs.txt)
+            for (unsigned q = 2; q <= nn && (unsigned)now * q <= 16; q++)
+                if (nn % q == 0 && pixelBlocks * now * q <= 8 * 4096 && a.mailboxOffset + (size_t)now * nn * 64 * 16 + (size_t)now * q * h->perWaveBytes(false) <= 48 * 1024) {
+                    chunks = q;
+                    if (pixelBlocks * now * q >= 4096)
+                        break;
+                }
+            if (const char* e = std::getenv("KAJO_SAMPLE_CHUNKS")) { // tuning knob
+                const unsigned v = (unsigned)std::atoi(e);
+                if (v >= 1 && v <= 16 && nn % v == 0 && (unsigned)now * v <= 16 && a.mailboxOffset + (size_t)now * nn * 64 * 16 <= 48 * 1024)
+                    chunks = v;
+            }
+            if ((unsigned)now * chunks <= split)
+                chunks = 1;
+        }
         hipError_t le;
-        if (split > 1) {
+        if (chunks > 1) {
+            RenderArgs b = a;
+            b.blockOrder = nullptr;
+            b.waveTrips = nullptr;
+            b.sampleChunks = (int32_t)chunks;
+            const unsigned waves = (unsigned)now * chunks;
+            h->fillWaveLds(b, a.mailboxOffset + (size_t)now * a.n * a.n * 64 * 16, false); // behind the [pass][sample][pixel] table
+            const size_t ldsSplit = b.perWaveOffset + (size_t)waves * b.perWaveBytes;
+            le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * waves, ldsSplit, h->stream)
+                                          : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * waves, ldsSplit, h->stream));
+        } else if (split > 1) {
             RenderArgs b = a;
             b.blockOrder = nullptr; // one round or two: the launch order does not matter
             b.waveTrips = nullptr;
@@ -630,7 +663,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         }
         HIP_TRY(hipEventRecord(e1, h->stream));
         h->pending.emplace_back(e0, e1);
-        if (a.waveTrips && split == 1) {
+        if (a.waveTrips && split == 1 && chunks == 1) {
             h->tripsPending = true;
             a.waveTrips = nullptr; // later launches of this call keep the first measurement
         }

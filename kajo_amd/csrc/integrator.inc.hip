@@ -871,8 +871,17 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     // ---- per-lane path state ----------------------------------------------------------------
     int mode = inImage ? MODE_NEW : MODE_DONE;
-    const int passesMine = SPLIT ? args.nPasses / splitCount : args.nPasses; // the host launches SPLIT only when this divides
-    const int firstMine = args.firstPass + splitWave * passesMine;
+    // SPLIT, second form (sampleChunks = Q > 1; launches of fewer passes than the block should have waves, e.g. BASELINE
+    // configs[0]: one pass): the block has nPasses * Q waves, wave w renders samples [q, q + 1) * n*n / Q (q = w % Q) of pass
+    // w / Q, and every PATH's radiance goes to the table, [pass][sample][pixel]; wave 0 then forms the passes' sums in sample
+    // order (Renderer.cpp:66) and adds the terms in pass order.
+    const int chunks = SPLIT ? args.sampleChunks : 0;
+    const bool bySample = SPLIT && chunks > 1;
+    const int passesMine = bySample ? 1 : (SPLIT ? args.nPasses / splitCount : args.nPasses); // the host launches SPLIT only when this divides
+    const int firstMine = args.firstPass + (bySample ? splitWave / chunks : splitWave * passesMine);
+    const int sampleBegin = bySample ? (splitWave % chunks) * (n * n / chunks) : 0;
+    const int sampleEnd = bySample ? sampleBegin + n * n / chunks : n * n; // (sampleY, sampleX) == (endY, endX): the lane's samples of the pass are done
+    const int endY = sampleEnd / n, endX = sampleEnd % n;
     int pass = firstMine;                       // pass being rendered (own or taken over)
     const int lastPass = firstMine + passesMine; // exclusive
     // Pass stealing. A pass of a pixel is a self-contained piece of work (its n*n paths have their own
@@ -885,7 +894,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     int myEnd = inImage ? lastPass : firstMine; // own passes [ownPass, myEnd); shrinks when one is taken over
     int stolenFrom = -1;          // lane whose pass is being rendered, or -1
     const int stealBase = lastPass - stealWindow > firstMine ? lastPass - stealWindow : firstMine;
-    int sampleX = 0, sampleY = 0;
+    int sampleX = sampleBegin % n, sampleY = sampleBegin / n;
     F3 radiance = f3(0.0f, 0.0f, 0.0f); // sum over the pixel's samples of this pass
     Rng rng{0, 0};
     F3 O = origin, d = f3(0.0f, 0.0f, 1.0f);
@@ -974,13 +983,15 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             }
         }
         if (!KAT && mode == MODE_NEW) {
-            if (sampleY == n) { // pass complete: Renderer.cpp:70-71
+            if (sampleY == endY && sampleX == endX) { // pass complete: Renderer.cpp:70-71
 #if KAJO_STRICT
                 const F3 term = f3(radiance.x / args.S, radiance.y / args.S, radiance.z / args.S);
 #else
                 const F3 term = radiance * invS;
 #endif
-                if (SPLIT) { // own or taken over: the term goes to the table, under its pass and pixel
+                if (bySample) { // (the paths' radiances are in the table already; this wave has no other pass)
+                    ownPass++;
+                } else if (SPLIT) { // own or taken over: the term goes to the table, under its pass and pixel
                     termTable[(pass - args.firstPass) * 64 + (stolenFrom >= 0 ? stolenFrom : lane)] = DFloat4{term.x, term.y, term.z, 0.0f};
                     if (stolenFrom >= 0)
                         stolenFrom = -1;
@@ -994,7 +1005,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     ownPass++;
                 }
                 radiance = f3(0.0f, 0.0f, 0.0f);
-                sampleY = 0;
+                sampleX = sampleBegin % n;
+                sampleY = sampleBegin / n;
                 pass = ownPass;
             }
             // out of own passes: take one over, or retire when nobody has one to give
@@ -1257,7 +1269,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
         KAJO_STAMP(3); // light loop + BSDF sampling block
         if (pathDone) {
-            radiance = radiance + L; // Renderer.cpp:66
+            if (bySample) // the path just finished is the one before the next sample to start
+                termTable[((pass - args.firstPass) * n * n + sampleY * n + sampleX - 1) * 64 + lane] = DFloat4{L.x, L.y, L.z, 0.0f};
+            else
+                radiance = radiance + L; // Renderer.cpp:66
             mode = MODE_NEW;
             if (KAT) {
                 reinterpret_cast<float4*>(args.katRgb)[slot] = make_float4(L.x, L.y, L.z, 0.0f);
@@ -1271,6 +1286,19 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         __syncthreads(); // every wave of the block has left its loop: the table is complete
         if (splitWave == 0 && inImage) {
             for (int p = 0; p < args.nPasses; p++) { // Renderer.cpp:70-71, pass by pass
+                if (bySample) {
+                    F3 sum = f3(0.0f, 0.0f, 0.0f);
+                    for (int k = 0; k < n * n; k++) { // Renderer.cpp:66, sample by sample
+                        const DFloat4 t = termTable[(p * n * n + k) * 64 + lane];
+                        sum = sum + f3(t.x, t.y, t.z);
+                    }
+#if KAJO_STRICT
+                    total = total + f3(sum.x / args.S, sum.y / args.S, sum.z / args.S);
+#else
+                    total = total + sum * invS;
+#endif
+                    continue;
+                }
                 const DFloat4 t = termTable[p * 64 + lane];
                 total = total + f3(t.x, t.y, t.z);
             }

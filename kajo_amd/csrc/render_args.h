@@ -21,6 +21,7 @@ struct RenderArgs
     int32_t tileIndex, tileCount, nTilesOwned;
     unsigned long long* counters; // [0] traversals, [1] vertices, [2] lane slots; may be null
     uint32_t mailboxOffset;       // byte offset of what follows the scene copy in dynamic LDS (16-byte aligned): the SPLIT kernels' term table
+    int32_t sampleChunks;         // SPLIT kernels: > 1 = every pass's n*n samples are divided over this many waves of the block (integrator.inc.hip)
     int32_t stealWindow;          // passes at the end of a launch an idle lane may take over (1..KAJO_STEAL_WINDOW_MAX): sizes the mailboxes
     // Per-wave LDS (integrator.inc.hip renderBody): wave w of the workgroup owns perWaveBytes at perWaveOffset + w * perWaveBytes:
     //   [0, ringOffset)            mailbox of taken-over passes, 64 lanes x stealWindow x float4   (absent in the SPLIT kernels)

@@ -43,6 +43,20 @@ def child(workload, mode, configs):
             k, v = item.split("=")
             os.environ[KEYS[k]] = v
         try:
+            if os.environ.get("KAJO_SWEEP_WALL"):  # no device counters (their per-wave atomics weigh on launches of many short waves): wall clock over 50 launches
+                import time
+                with HipRenderer(sc, W, H, spp=S, depth_limit=depth, strict=(mode == "strict"), passes_per_launch=passes) as r:
+                    r.render(passes).wait()
+                    r.render(passes).wait()
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        r.render(passes)
+                    r.wait()
+                    dt = (time.perf_counter() - t0) / 50
+                print("%-14s %-6s %-36s %9.1f Mpaths/s  wall %8.3f ms per launch (50 launches back to back, no counters)" % (
+                    os.path.basename(capi.LIB_PATH).replace("libkajo_hip", "lib").replace(".so", ""), mode, cfg or "(defaults)",
+                    W * H * int(S ** .5) ** 2 * passes / dt / 1e6, dt * 1e3), flush=True)
+                continue
             with HipRenderer(sc, W, H, spp=S, depth_limit=depth, strict=(mode == "strict"), counters=True, passes_per_launch=passes) as r:
                 r.render(passes).wait()
                 r.render(passes).wait()

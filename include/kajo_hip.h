@@ -104,9 +104,11 @@ int kajo_hip_render(kajo_hip_t h, int passes);
 int kajo_hip_wait(kajo_hip_t h);
 /* Zero the accumulation and restart the pass numbering at 1. */
 int kajo_hip_reset(kajo_hip_t h);
-/* Continue the pass numbering from `passesDone` (the next pass rendered is passesDone + 1) without touching the
-   accumulation: the reference's loop `for (pass = 1;; pass++)` (Renderer.cpp:44) has no end, and a progressive
-   session may be carried on from any pass number. Pass numbers run to 2^31 - 1 (include/kajo_stream.h). */
+/* Continue a progressive session from pass `passesDone`: the next pass rendered is passesDone + 1 (the reference's loop
+   `for (pass = 1;; pass++)`, Renderer.cpp:44, has no end). The call does not touch the accumulation buffer and DECLARES
+   that it holds the sum of `passesDone` passes: kajo_hip_resolve_* divide by the pass count and kajo_hip_counters reports
+   it, so the caller restores the buffer of the session being continued through kajo_hip_tile_buffer() first (or calls
+   kajo_hip_reset() and set_pass_count(0)). Pass numbers run to 2^31 - 2. */
 int kajo_hip_set_pass_count(kajo_hip_t h, int passesDone);
 
 /* Whole-frame outputs; valid when tileCount == 1, or on a handle that has been composed.

@@ -534,8 +534,10 @@ int kajo_hip_render(kajo_hip_t h, int passes)
 {
     if (!h)
         return fail(KAJO_E_INVALID, "null handle");
-    if (passes < 0 || h->passesDone + (long long)passes > 0x7fffffffll)
-        return fail(KAJO_E_INVALID, "pass count out of range (2^31 - 1 passes per handle)");
+    // (the kernels form the exclusive end of a launch's passes, firstPass + nPasses, in 32-bit integers: the last pass number a
+    // handle can render is 2^31 - 2)
+    if (passes < 0 || h->passesDone + (long long)passes > 0x7ffffffell)
+        return fail(KAJO_E_INVALID, "pass count out of range (pass numbers run to 2^31 - 2)");
     int rc = bind(h);
     if (rc)
         return rc;
@@ -735,7 +737,7 @@ int kajo_hip_reset(kajo_hip_t h)
 
 int kajo_hip_set_pass_count(kajo_hip_t h, int passesDone)
 {
-    if (!h || passesDone < 0)
+    if (!h || passesDone < 0 || passesDone > 0x7ffffffe)
         return fail(KAJO_E_INVALID, "invalid argument");
     int rc = kajo_hip_wait(h);
     if (rc)

@@ -112,17 +112,26 @@ def test_fast_on_caustics_and_stress(scenes):
 
 def test_maximum_sizes(scenes):
     """4K frame (BASELINE configs[2] size): every tile is written, a crop agrees with the oracle bit for bit
-    (STRICT), two runs agree; and the pass counter refuses to run past 2^31 - 1."""
+    (STRICT), two runs agree; and the pass counter refuses to run past 2^31 - 2, the last pass number the kernels' 32-bit
+    pass arithmetic can end a launch on -- while that last pass itself is rendered, bit for bit the oracle's."""
     from kajo_amd import capi
     sc = scenes["spheres_a169"]
     W, H = 3840, 2160
     with HipRenderer(sc, W, H, spp=4, strict=True) as r:
         a = r.render(1).radiance()
-        r.set_pass_count(2 ** 31 - 2)
+        r.set_pass_count(2 ** 31 - 3)
         with pytest.raises(capi.KajoError) as e:
             r.render(2)
         assert e.value.code == -1
         r.set_pass_count(1)
+    # the last renderable pass, number 2^31 - 2, on a small frame: equal to the oracle's pass of that number
+    with HipRenderer(scenes["spheres_a1"], 40, 24, spp=16, strict=True) as r:
+        r.set_pass_count(2 ** 31 - 3)
+        last = r.render(1).radiance()
+        with pytest.raises(capi.KajoError):
+            r.render(1)
+    want_last = OracleLib("oracle").create(scenes["spheres_a1"], 1).render(40, 24, S=16, passes=1, seed=SEED, first_pass=2 ** 31 - 2)
+    assert ((last[..., :3].view(np.uint32) == want_last[..., :3].view(np.uint32)) | (np.isnan(last[..., :3]) & np.isnan(want_last[..., :3]))).all()
     assert np.isfinite(a[..., :3]).mean() > 0.9999 and (a[..., :3] != 0).any(axis=(0, 2)).all()
     x0, y0, w, h = 3700, 2100, 96, 48   # bottom-right corner region (last tiles, partial tile row)
     want = OracleLib("oracle").create(sc, 1).render(W, H, S=4, passes=1, seed=SEED, rect=(x0, y0, w, h))[y0:y0 + h, x0:x0 + w, :3]
@@ -164,3 +173,28 @@ def test_scaled_spheres_in_a_large_scene_keep_the_every_sphere_walk(scenes):
     sc2 = Scene(sc.background, sc.view, sc.proj, sph, sc.planes, "scaled among 60")
     strict_equal(sc2, 64, 36, S=4, passes=2)
     fast_close(sc2, 64, 36, S=4, passes=2, slack=2.5)
+
+
+def test_set_pass_count_continues_a_restored_session(scenes):
+    """kajo_hip_set_pass_count declares that the accumulation buffer holds the sum of that many passes (include/kajo_hip.h): a
+    session continued on a fresh handle -- buffer restored through kajo_hip_tile_buffer, pass count set -- resolves to exactly
+    the image of the uninterrupted session, and its counters report the passes the buffer stands for."""
+    import torch
+    from bench import DevicePtr
+    sc = scenes["spheres_a1"]
+    W, H = 64, 48
+    with HipRenderer(sc, W, H, spp=16, strict=True) as a:
+        a.render(3).wait()
+        ptr, nbytes = a.tile_buffer()
+        saved = torch.as_tensor(DevicePtr(ptr, nbytes // 4), device="cuda").clone()
+        whole = a.render(2).radiance()
+        px_whole = a.argb8()
+    with HipRenderer(sc, W, H, spp=16, strict=True) as b:
+        ptr, nbytes = b.tile_buffer()
+        torch.as_tensor(DevicePtr(ptr, nbytes // 4), device="cuda").copy_(saved)
+        torch.cuda.synchronize()
+        b.set_pass_count(3)
+        got = b.render(2).radiance()
+        assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
+        assert np.array_equal(b.argb8(), px_whole)
+        assert b.counters()["passes"] == 5

@@ -259,3 +259,20 @@ def test_pass_splitting_over_waves_is_bit_invariant(O, scenes, passes):
     want = O.create(sc, 1).render(W, H, S=32, passes=passes, seed=0o715517, depth_limit=8)
     with HipRenderer(sc, W, H, strict=True, passes_per_launch=16) as r:
         assert bits_equal(r.render(passes).radiance(), want)
+
+
+@pytest.mark.parametrize("S,ppl,passes", [(16, 1, 3), (32, 1, 2), (32, 2, 4), (9, 3, 3), (36, 1, 1)])
+def test_sample_splitting_over_waves_is_bit_invariant(O, scenes, S, ppl, passes):
+    """Small frames, launches of few passes (BASELINE configs[0]: ONE pass): the waves of a block divide the n*n samples of a
+    pass; every path's radiance goes to an LDS table [pass][sample][pixel] and wave 0 forms the sums in sample order
+    (Renderer.cpp:66), so the buffer is the one a single wave per block produces -- FAST bit for bit against
+    KAJO_FLAG_NO_SPLIT, STRICT against the oracle; the accumulation continues across launches."""
+    from kajo_amd import capi
+    sc = scenes["spheres_a169"]
+    W, H = 72, 40  # 45 pixel blocks, ragged
+    with HipRenderer(sc, W, H, spp=S, passes_per_launch=ppl) as a, HipRenderer(sc, W, H, spp=S, passes_per_launch=ppl, flags=capi.KAJO_FLAG_NO_SPLIT) as b:
+        assert bits_equal(a.render(passes).radiance(), b.render(passes).radiance())
+        assert bits_equal(a.render(1).radiance(), b.render(1).radiance())
+    want = O.create(sc, 1).render(W, H, S=S, passes=passes, seed=0o715517, depth_limit=8)
+    with HipRenderer(sc, W, H, spp=S, strict=True, passes_per_launch=ppl) as r:
+        assert bits_equal(r.render(passes).radiance(), want)

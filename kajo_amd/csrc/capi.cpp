@@ -416,9 +416,13 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     if (h->deferred) {
         envInt("KAJO_STASH_DEPTH", 1, 4, h->stashDepth);
         envInt("KAJO_RING_SLOTS", 1, 8, h->ringSlots);
-        envInt("KAJO_THR_L", 1, 65, h->thrL);
         envInt("KAJO_THR_STALL", 1, 65, h->thrStall);
+    } else {
+        // STRICT loop (integrator.inc.hip MODE_HOLD): lanes that must want the light / BSDF blocks before they run without any
+        // lane having waited; 1 = every trip. Large scenes run them every trip (16 lights: most lanes are in them anyway).
+        h->thrL = (h->strict() && !big) ? 24 : 1;
     }
+    envInt("KAJO_THR_L", 1, 65, h->thrL);
     if (h->deferred && (!pow2(h->stashDepth) || !pow2(h->ringSlots))) {
         destroy(h);
         return fail(KAJO_E_INVALID, "KAJO_STASH_DEPTH and KAJO_RING_SLOTS must be powers of two");

@@ -709,7 +709,8 @@ enum : int
     MODE_NEW = 0,    // fetch the next camera path of this lane's pixel
     MODE_EXTEND = 1, // the traced ray continues the path: shade what it hit
     MODE_SHADOW = 2, // the traced ray asks whether light `lightK` is visible
-    MODE_DONE = 3
+    MODE_DONE = 3,
+    MODE_HOLD = 4    // the vertex waits for a trip in which the light / BSDF sampling blocks run (RenderArgs::thrL)
 };
 
 } // namespace
@@ -1081,7 +1082,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             ctrSlots += 64;
         }
 
-        bool sampleNext = false; // continue with the light loop / BSDF sampling of vertex v*
+        bool sampleNext = KAJO_STRICT && mode == MODE_HOLD; // continue with the light loop / BSDF sampling of vertex v*
         bool pathDone = false;
         KAJO_PROF(1, mode == MODE_EXTEND && pendBsdf && hit.id > np);
         KAJO_PROF(2, mode == MODE_EXTEND && hit.id != 0);
@@ -1182,6 +1183,18 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
 
         KAJO_STAMP(2); // vertex / shadow-result block
+#if KAJO_STRICT
+        // STRICT: the light / BSDF sampling blocks are 40 % of a trip's instructions (binary32 sin/cos/asin series, IEEE
+        // divisions) and run with a quarter of the lanes. They run in this trip if at least thrL lanes want them, or if some
+        // lane has waited a trip already (no vertex waits twice); lanes that want them in a trip without them sit the next
+        // traversal out. Measured (profiles/r03_hold_sweep.txt): thrL = 24 is +7.5 % on configs[1]; FAST, whose blocks are a
+        // third as long, gains nothing (and pays 2 % for the bookkeeping), so its loop runs them in every trip.
+        const unsigned long long wantL = __ballot(sampleNext);
+        const bool runL = __builtin_popcountll(wantL) >= args.thrL || __ballot(mode == MODE_HOLD) != 0ull;
+        if (sampleNext && !runL)
+            mode = MODE_HOLD;
+        sampleNext = sampleNext && runL;
+#endif
         KAJO_PROF(5, sampleNext);
         if (sampleNext) {
             const DMaterial& vm = lds.material[vId - 1];

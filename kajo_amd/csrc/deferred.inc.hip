@@ -476,6 +476,9 @@ KDEV void renderBodyDeferred(const RenderArgs& args, unsigned char* ldsRaw)
             mode = extOk ? DM_EXTEND : DM_RETIRE;
         } else if (mode == DM_EXTEND) {
             // ---- E work, after the ray: the vertex (Shader.cpp:113-178) -----------------------------------
+            const DFloat4* mq = reinterpret_cast<const DFloat4*>(lds.material + (hit.id > 0 ? hit.id - 1 : 0));
+            const DFloat4 m0 = mq[0], m1 = mq[1];
+            const uint32_t m1flags = __builtin_bit_cast(uint32_t, m1.w);
             // Weight of the BSDF-sampled segment that just ended (Shader.cpp:203-212). The throughput was
             // advanced with a zero light pdf when the direction was sampled (0 + p == p exactly); only a ray
             // that lands on a light other than the vertex it left needs the MIS denominator pL + p.
@@ -484,13 +487,12 @@ KDEV void renderBodyDeferred(const RenderArgs& args, unsigned char* ldsRaw)
                 // that reaches it, and a path that arrives over a BSDF-sampled segment collects no emission there
                 // (Shader.cpp:121,212): its throughput is never used again, so the MIS correction is skipped. STRICT
                 // keeps it when the throughput is not finite: NaN * 0 must stay NaN.)
-                const DMaterial& hm = lds.material[hit.id > 0 ? hit.id - 1 : 0];
 #if KAJO_STRICT
-                const bool weightMatters = hm.pRR != 0.0f || !(__builtin_fabsf(T.x) < __builtin_inff() && __builtin_fabsf(T.y) < __builtin_inff() && __builtin_fabsf(T.z) < __builtin_inff());
+                const bool weightMatters = m0.x != 0.0f || !(__builtin_fabsf(T.x) < __builtin_inff() && __builtin_fabsf(T.y) < __builtin_inff() && __builtin_fabsf(T.z) < __builtin_inff());
 #else
-                const bool weightMatters = hm.pRR != 0.0f;
+                const bool weightMatters = m0.x != 0.0f;
 #endif
-                if (hit.id > np && hit.id != vId && hm.isLight && weightMatters) {
+                if (hit.id > np && hit.id != vId && (m1flags & KAJO_MAT_IS_LIGHT) && weightMatters) {
                     const DSphereCold& lc = lds.sphereCold[hit.id - 1 - np];
 #if KAJO_STRICT
                     const float pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));
@@ -510,28 +512,31 @@ KDEV void renderBodyDeferred(const RenderArgs& args, unsigned char* ldsRaw)
             } else {
                 if (counting)
                     ctrVertices += 1;
-                const DMaterial& m = lds.material[hit.id - 1];
                 const F3 view = d;
                 vP = O + d * hit.t; // Raytracer.cpp:134-135
                 const F3 vN = hitNormal(sc, lds, hit, O, d);
                 vId = hit.id;
-                const F3 em = collectEmission ? ld3(m.emission) : f3(0.0f, 0.0f, 0.0f); // Shader.cpp:121
+                const F3 em = collectEmission ? f3(m1.x, m1.y, m1.z) : f3(0.0f, 0.0f, 0.0f); // Shader.cpp:121
                 float pc;
-                const bool cont = flipCoin(rng, m.pRR, pc); // Shader.cpp:124-125
+                const bool cont = flipCoin(rng, m0.x, pc); // Shader.cpp:124-125
                 if (!cont || depth >= args.depthLimit) {
                     // Shader.cpp:126-127: 1 / pc with pc = pRR (depth limit) or 1 - pRR (the coin said stop), formed on the host
-                    L = L + T * ((cont ? m.sDepth : m.sStop) * em);
+                    float sEnd = m0.w;
+                    if (cont)
+                        sEnd = mq[4].w;
+                    L = L + T * (sEnd * em);
                     mode = DM_RETIRE;
                 } else {
                     float pt;
-                    const bool transparent = flipCoin(rng, m.pT, pt); // Shader.cpp:130-134
+                    const bool transparent = flipCoin(rng, m0.y, pt); // Shader.cpp:130-134
                     KAJO_PROF(5, transparent);
                     if (transparent) { // Shader.cpp:137-151; the BSDF colour is the SPECULAR colour
-                        F3 nd = transmissionDirection(view, vN, m.ior);
+                        const DFloat4 m2 = mq[2], m4 = mq[4];
+                        F3 nd = transmissionDirection(view, vN, m2.w);
                         float cosA = __builtin_fabsf(dot(nd, vN));
-                        F3 spec = ld3(m.specular);
+                        F3 spec = f3(m2.x, m2.y, m2.z);
                         F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
-                        F3 w = (m.sTransparent * f) * __builtin_fabsf(dot(vN, nd)); // sTransparent = 1/pc * 1/pt
+                        F3 w = (m4.z * f) * __builtin_fabsf(dot(vN, nd)); // sTransparent = 1/pc * 1/pt
                         L = L + T * (w * em);
                         T = T * w;
                         O = vP + nd * kEps;
@@ -542,8 +547,8 @@ KDEV void renderBodyDeferred(const RenderArgs& args, unsigned char* ldsRaw)
                         // The vertex survives and wants its lights and a BSDF sample: park it (the lane had a free slot
                         // when it traced this ray) and free the registers for the pixel's next camera path.
                         float pd;
-                        const bool diffuse = flipCoin(rng, m.pD, pd); // Shader.cpp:153-154
-                        const uint32_t vKind = diffuse ? 0u : (m.exponent != 0.0f ? 1u : 2u);
+                        const bool diffuse = flipCoin(rng, m0.z, pd); // Shader.cpp:153-154
+                        const uint32_t vKind = diffuse ? 0u : ((m1flags & KAJO_MAT_HAS_EXPONENT) ? 1u : 2u);
                         KAJO_PROF(6, true);
                         DFloat4* e = stash + (size_t)((stashHead + stashCount) & (stashDepth - 1)) * (KAJO_STASH_QUADS * 64);
                         const uint32_t pk0 = (uint32_t)vId | ((uint32_t)depth << 18) | (collectEmission ? 1u << 28 : 0u) | (vKind << 29);

@@ -29,25 +29,34 @@ struct DFloat4
     float x, y, z, w;
 };
 
-struct DMaterial // 24 floats
+// 24 floats = 6 float4, grouped by WHEN the integrator needs them, so that each stage of a vertex is one or two 16-byte
+// reads issued together (an LDS round trip is ~100 cycles of a wave that has nothing else to issue; round 2's layout cost the
+// vertex block seven of them, one per field group in member order of scene::Material):
+//   q0 the three coins of Shader.cpp:124,130-134,153 and the scale of a path the first coin stops
+//   q1 emission (every vertex adds it, Shader.cpp:121) and two flags
+//   q2 specular colour + index of refraction (the refraction branch, Shader.cpp:137-151)
+//   q3 diffuse colour + Phong exponent, q4 the path-weight scales (light / BSDF sampling, Shader.cpp:160-177)
+#define KAJO_MAT_IS_LIGHT 1u     /* emission != vec4(0), Shader.cpp:57 */
+#define KAJO_MAT_HAS_EXPONENT 2u /* specularExponent != 0: Phong lobe, else the ideal reflector (Shader.cpp:155-158) */
+struct DMaterial
 {
-    float diffuse[3];
     float pRR;      // max over rgb of max(diffuse, specular, transparency)   (Shader.cpp:124-125)
-    float specular[3];
     float pT;       // sum(transparency) / (sum d + sum s + sum t)            (Shader.cpp:130-133)
-    float emission[3];
     float pD;       // sum(diffuse) / (sum d + sum s)                         (Shader.cpp:153)
-    float transparency[3];
-    float exponent;
+    float sStop;    // 1 / (1 - pRR): Russian roulette said stop              (Shader.cpp:126-127)
+    float emission[3];
+    uint32_t flags; // KAJO_MAT_*
+    float specular[3];
     float ior;
-    uint32_t isLight; // emission != vec4(0)                                  (Shader.cpp:57)
-    // FAST numerics only: the path-weight scales of Shader.cpp:146-147,160-177, which depend only on
-    // the material and on which way the coins fell
-    float sTransparent; // 1 / (pRR * pT)
-    float sDiffuse;     // 1 / (pRR * (1 - pT) * pD)
-    float sSpecular;    // 1 / (pRR * (1 - pT) * (1 - pD))
-    float sStop;        // 1 / (1 - pRR): Russian roulette said stop
+    float diffuse[3];
+    float exponent;
+    // the path-weight scales of Shader.cpp:146-147,160-177, which depend only on the material and on which way the coins
+    // fell; formed on the host in the reference's operation order (exact in both numerics modes)
+    float sDiffuse;     // 1 / pRR * 1 / (1 - pT) * 1 / pD
+    float sSpecular;    // 1 / pRR * 1 / (1 - pT) * 1 / (1 - pD)
+    float sTransparent; // 1 / pRR * 1 / pT
     float sDepth;       // 1 / pRR: depth limit reached
+    float transparency[3];
     float pad;
 };
 

@@ -1089,6 +1089,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         KAJO_PROF(6, mode == MODE_SHADOW);
 
         if (mode == MODE_EXTEND) {
+            // the hit object's material: coins and emission in one round trip (device_scene.h)
+            const DFloat4* mq = reinterpret_cast<const DFloat4*>(lds.material + (hit.id > 0 ? hit.id - 1 : 0));
+            const DFloat4 m0 = mq[0], m1 = mq[1];
+            const uint32_t m1flags = __builtin_bit_cast(uint32_t, m1.w);
             // Weight of the BSDF-sampled segment that just ended (Shader.cpp:203-212). The throughput was
             // advanced with a zero light pdf when the direction was sampled (0 + p == p exactly); only a ray
             // that lands on a light other than the vertex it left needs the MIS denominator pL + p.
@@ -1097,13 +1101,12 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // that reaches it, and a path that arrives over a BSDF-sampled segment collects no emission there
                 // (Shader.cpp:121,212): its throughput is never used again, so the MIS correction is skipped. STRICT
                 // keeps it when the throughput is not finite: NaN * 0 must stay NaN.)
-                const DMaterial& hm = lds.material[hit.id > 0 ? hit.id - 1 : 0];
 #if KAJO_STRICT
-                const bool weightMatters = hm.pRR != 0.0f || !(__builtin_fabsf(T.x) < __builtin_inff() && __builtin_fabsf(T.y) < __builtin_inff() && __builtin_fabsf(T.z) < __builtin_inff());
+                const bool weightMatters = m0.x != 0.0f || !(__builtin_fabsf(T.x) < __builtin_inff() && __builtin_fabsf(T.y) < __builtin_inff() && __builtin_fabsf(T.z) < __builtin_inff());
 #else
-                const bool weightMatters = hm.pRR != 0.0f;
+                const bool weightMatters = m0.x != 0.0f;
 #endif
-                if (hit.id > np && hit.id != vId && hm.isLight && weightMatters) {
+                if (hit.id > np && hit.id != vId && (m1flags & KAJO_MAT_IS_LIGHT) && weightMatters) {
                     const DSphereCold& lc = lds.sphereCold[hit.id - 1 - np];
 #if KAJO_STRICT
                     const float pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));
@@ -1126,30 +1129,33 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             } else {
                 if (counting)
                     ctrVertices += 1;
-                const DMaterial& m = lds.material[hit.id - 1];
                 const F3 view = d;
                 vP = O + d * hit.t; // Raytracer.cpp:134-135
                 vN = hitNormal(sc, lds, hit, O, d);
                 vId = hit.id;
-                vE = collectEmission ? ld3(m.emission) : f3(0.0f, 0.0f, 0.0f); // Shader.cpp:121
+                vE = collectEmission ? f3(m1.x, m1.y, m1.z) : f3(0.0f, 0.0f, 0.0f); // Shader.cpp:121
                 float pc;
-                const bool cont = flipCoin(rng, m.pRR, pc); // Shader.cpp:124-125
+                const bool cont = flipCoin(rng, m0.x, pc); // Shader.cpp:124-125
                 if (!cont || depth >= args.depthLimit) {
                     // Shader.cpp:126-127: 1 / pc with pc = pRR (depth limit) or 1 - pRR (the coin said stop). The quotient depends on
                     // the material only and is formed on the host in the reference's order (stage.cpp), in both numerics modes.
-                    L = L + T * ((cont ? m.sDepth : m.sStop) * vE);
+                    float sEnd = m0.w;
+                    if (cont)
+                        sEnd = mq[4].w;
+                    L = L + T * (sEnd * vE);
                     pathDone = true;
                 } else {
                     float pt;
-                    const bool transparent = flipCoin(rng, m.pT, pt); // Shader.cpp:130-134
+                    const bool transparent = flipCoin(rng, m0.y, pt); // Shader.cpp:130-134
                     KAJO_PROF(3, transparent);
                     KAJO_PROF(4, !transparent);
                     if (transparent) { // Shader.cpp:137-151; the BSDF colour is the SPECULAR colour
-                        F3 nd = transmissionDirection(view, vN, m.ior);
+                        const DFloat4 m2 = mq[2], m4 = mq[4];
+                        F3 nd = transmissionDirection(view, vN, m2.w);
                         float cosA = __builtin_fabsf(dot(nd, vN));
-                        F3 spec = ld3(m.specular);
+                        F3 spec = f3(m2.x, m2.y, m2.z);
                         F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
-                        F3 w = (m.sTransparent * f) * __builtin_fabsf(dot(vN, nd)); // sTransparent = 1/pc * 1/pt, Shader.cpp:146-147
+                        F3 w = (m4.z * f) * __builtin_fabsf(dot(vN, nd)); // sTransparent = 1/pc * 1/pt, Shader.cpp:146-147
                         L = L + T * (w * vE);
                         T = T * w;
                         O = vP + nd * kEps;
@@ -1158,8 +1164,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         // mode stays MODE_EXTEND, the light sampling scheme is inherited
                     } else {
                         float pd;
-                        const bool diffuse = flipCoin(rng, m.pD, pd); // Shader.cpp:153-154
-                        vKind = diffuse ? 0 : (m.exponent != 0.0f ? 1 : 2);
+                        const bool diffuse = flipCoin(rng, m0.z, pd); // Shader.cpp:153-154
+                        vKind = diffuse ? 0 : ((m1flags & KAJO_MAT_HAS_EXPONENT) ? 1 : 2);
                         vR = reflect(view, vN);
 #if KAJO_STRICT
                         vLd = f3(0.0f, 0.0f, 0.0f);
@@ -1197,10 +1203,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #endif
         KAJO_PROF(5, sampleNext);
         if (sampleNext) {
-            const DMaterial& vm = lds.material[vId - 1];
-            const F3 vColor = vKind == 0 ? ld3(vm.diffuse) : ld3(vm.specular);
-            const float vExp = vm.exponent;
-            const float vSl = vKind == 0 ? vm.sDiffuse : vm.sSpecular; // 1/pc * 1/pt * 1/pd, Shader.cpp:160-177
+            const DFloat4* vq = reinterpret_cast<const DFloat4*>(lds.material + (vId - 1));
+            const DFloat4 v2 = vq[2], v3 = vq[3], v4 = vq[4];
+            const F3 vColor = vKind == 0 ? f3(v3.x, v3.y, v3.z) : f3(v2.x, v2.y, v2.z);
+            const float vExp = v3.w;
+            const float vSl = vKind == 0 ? v4.x : v4.y; // 1/pc * 1/pt * 1/pd, Shader.cpp:160-177
             // ---- sampleLights (Shader.cpp:50-86), one light per trip ------------------------------
             bool shadowRay = false;
             while (lightK < sc.nLights) {

@@ -155,7 +155,8 @@ DMaterial stageMaterial(const KajoMaterial& k)
     d.pD = sd / (sd + ss);
     d.exponent = k.specularExponent;
     d.ior = k.refractiveIndex;
-    d.isLight = !(k.emission[0] == 0 && k.emission[1] == 0 && k.emission[2] == 0 && k.emission[3] == 0);
+    d.flags = (!(k.emission[0] == 0 && k.emission[1] == 0 && k.emission[2] == 0 && k.emission[3] == 0) ? KAJO_MAT_IS_LIGHT : 0u) |
+              (k.specularExponent != 0.0f ? KAJO_MAT_HAS_EXPONENT : 0u);
     d.sTransparent = 1.f / d.pRR * 1.f / d.pT;
     d.sDiffuse = 1.f / d.pRR * 1.f / (1.f - d.pT) * 1.f / d.pD;
     d.sSpecular = 1.f / d.pRR * 1.f / (1.f - d.pT) * 1.f / (1.f - d.pD);
@@ -362,7 +363,7 @@ void stageScene(const KajoScene& s, StagedScene& out, int gridMinSpheres)
         out.sphereCold.push_back(cold);
         DMaterial m = stageMaterial(s.spheres[i].material);
         out.material.push_back(m);
-        if (m.isLight)
+        if (m.flags & KAJO_MAT_IS_LIGHT)
             out.light.push_back(i);
     }
 

@@ -362,11 +362,23 @@ KDEV void renderBodyDeferred(const RenderArgs& args, unsigned char* ldsRaw)
             // ---- sampleLights (Shader.cpp:50-86), one light per visit ------------------------------
             bool shadowRay = false;
             while (lightK < sc.nLights) {
-                const int si = lds.light[lightK];
-                if (np + 1 + si == vId) { // a light does not sample itself
-                    lightK++;
-                    continue;
+                // Lights whose sample is discarded whatever it is -- the ideal reflector asks for none (its pdf toward any
+                // given direction is 0, BSDF.cpp:93-96), and a light that lies wholly below the vertex's horizon has
+                // max(0, n.l) = 0 for every point of it -- only draw their random number (Light.cpp:39-41: one draw per
+                // sample), in a loop of its own: the full sampling code below then runs for lights that can count.
+                for (; lightK < sc.nLights; lightK++) {
+                    const int sk = lds.light[lightK];
+                    if (np + 1 + sk == vId) // a light does not sample itself (and draws nothing)
+                        continue;
+                    const DSphereCold& lk = lds.lightCold[lightK];
+                    const F3 toC = f3(lk.cx - vP.x, lk.cy - vP.y, lk.cz - vP.z);
+                    const bool below = dot(vN, toC) < -(1.001f * lk.radius + 1e-6f * (__builtin_fabsf(toC.x) + __builtin_fabsf(toC.y) + __builtin_fabsf(toC.z)));
+                    if (!(vKind == 2 || below))
+                        break;
+                    rngStep(rng);
                 }
+                if (lightK >= sc.nLights)
+                    break;
                 const DSphereCold& lc = lds.lightCold[lightK];
                 float pl;
                 // written straight into the ray: a discarded sample leaves d and O to the next light or to the BSDF sample
@@ -391,7 +403,7 @@ KDEV void renderBodyDeferred(const RenderArgs& args, unsigned char* ldsRaw)
                 const DFloat4 le = lds.lightEmission[lightK];
                 const F3 Le = f3(le.x, le.y, le.z);
                 pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
-                lightObj = np + 1 + si;
+                lightObj = np + 1 + lds.light[lightK];
                 shadowRay = true;
                 break;
             }

@@ -172,6 +172,9 @@ struct LdsScene
     const int32_t* light;          // [nLights] sphere indices, always in LDS
     const DSphereCold* lightCold;  // [nLights] the lights' own cold records and
     const DFloat4* lightEmission;  // [nLights] emissions, always in LDS: a large scene's light loop reads nothing from global memory
+    const DFloat4* camera;         // [7] p1, p2 - p1, p3 - p1, origin (Renderer.cpp:29-34), background, the pixel / sample sizes of
+                                   // Renderer.cpp:39-42, stream key words + W + H: read where a camera ray is formed /
+                                   // a ray escapes, instead of fifteen scalar registers held through the whole loop (the loop spills SGPRs)
     const uint32_t* gridCellStart; // LDS copy when it fits (DGrid.inLds), else the global arrays
     const uint16_t* gridItems;
 };
@@ -745,7 +748,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     const int np = sc.nPlanes, ns = sc.nSpheres;
     // layout: [planeRow np x16][sphereHot nHot x16]{[planeFrame 3np x16][sphereCold ns x64]
     //         [material (np+ns) x96]}[planeDet np x4][sphereHotOffset ns x4][light nL x4] (pad to 16)
-    //         [lightCold nL x64][lightEmission nL x16]{[grid cell starts][grid items]}
+    //         [lightCold nL x64][lightEmission nL x16][camera 7 x16]{[grid cell starts][grid items]}
     DFloat4* ldsPlaneRow = reinterpret_cast<DFloat4*>(ldsRaw);
     DFloat4* ldsSphereHot = ldsPlaneRow + np;
     DFloat4* cursor = ldsSphereHot + sc.nSphereHot;
@@ -792,13 +795,22 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
         const DMaterial& lm = sc.material[np + sc.light[i]];
         le4[i] = DFloat4{lm.emission[0], lm.emission[1], lm.emission[2], 0.0f};
     }
+    DFloat4* cam4 = le4 + sc.nLights;
+    if (threadIdx.x == 0) {
+        cam4[0] = DFloat4{sc.p1[0], sc.p1[1], sc.p1[2], 0.0f};
+        cam4[1] = DFloat4{sc.dp2[0], sc.dp2[1], sc.dp2[2], 0.0f};
+        cam4[2] = DFloat4{sc.dp3[0], sc.dp3[1], sc.dp3[2], 0.0f};
+        cam4[3] = DFloat4{sc.origin[0], sc.origin[1], sc.origin[2], 0.0f};
+        cam4[4] = DFloat4{sc.background[0], sc.background[1], sc.background[2], 0.0f};
+    }
+    lds.camera = cam4; // (cam4[5], cam4[6] are the launch's, written by renderBody)
     lds.lightCold = reinterpret_cast<const DSphereCold*>(lc4);
     lds.lightEmission = le4;
     lds.gridCellStart = sc.grid.cellStart;
     lds.gridItems = sc.grid.items;
     if (!COLD_LDS && sc.grid.enabled && sc.grid.inLds) {
         // the DDA reads two cell offsets per step: from LDS that is ~64 cycles, from L2 ~500
-        uint32_t* cs = reinterpret_cast<uint32_t*>(le4 + sc.nLights);
+        uint32_t* cs = reinterpret_cast<uint32_t*>(cam4 + 7);
         uint16_t* it = reinterpret_cast<uint16_t*>(cs + sc.grid.nCells + 1);
         for (int i = threadIdx.x; i <= sc.grid.nCells; i += blockDim.x)
             cs[i] = sc.grid.cellStart[i];
@@ -826,6 +838,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
+    if (threadIdx.x == 0) { // what only the camera-ray block needs of the launch: kept out of the scalar registers
+        DFloat4* cam = const_cast<DFloat4*>(lds.camera);
+        cam[5] = DFloat4{args.pixelWidth, args.pixelHeight, args.sampleWidth, args.sampleHeight};
+        cam[6] = DFloat4{__builtin_bit_cast(float, (uint32_t)args.seed ^ 0x79622d32u), __builtin_bit_cast(float, (uint32_t)(args.seed >> 32) ^ 0x6b206574u),
+                         __builtin_bit_cast(float, args.W), __builtin_bit_cast(float, args.H)};
+    }
+    __syncthreads();
 
     // per-wave mailbox for taken-over passes: [lane][stealWindow] float4, behind the scene copy (render_args.h)
     const int stealWindow = args.stealWindow;
@@ -852,13 +871,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     const int n = args.n;
     // include/kajo_stream.h: key words (pixel, sample | pass << 16, seed lo ^ pass >> 16, seed hi) ^ constants
-    const uint32_t keyC = (uint32_t)args.seed ^ 0x79622d32u;
-    const uint32_t keyD = (uint32_t)(args.seed >> 32) ^ 0x6b206574u;
     // first pixel of the wave's 8x8 block: the pixel of lane l is (blockX + (l & 7), blockY + (l >> 3))
     const int blockX = __builtin_amdgcn_readfirstlane(px - (lane & 7)), blockY = __builtin_amdgcn_readfirstlane(py - (lane >> 3));
 
-    const F3 p1 = ld3(sc.p1), dp2 = ld3(sc.dp2), dp3 = ld3(sc.dp3), origin = ld3(sc.origin);
-    const F3 background = ld3(sc.background);
+    const F3 origin = ld3(sc.origin); // (initial values only: the loop reads the camera from lds.camera)
     // accumulated radiance of the pixel (Renderer.cpp:70-71), continued across launches
     // (the handle zeroes the buffer when it is created or reset)
     F3 total = f3(0.0f, 0.0f, 0.0f);
@@ -1037,8 +1053,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // rather than carried in six registers through the whole loop.
                 const int srcLane = stolenFrom >= 0 ? stolenFrom : lane;
                 const int spx = blockX + (srcLane & 7), spy = blockY + (srcLane >> 3);
-                const float curPixX = spx * args.pixelWidth, curPixY = (args.H - spy) * args.pixelHeight;
-                uint32_t a = (uint32_t)(spy * args.W + spx) ^ 0x61707865u, c = keyC ^ ((uint32_t)pass >> 16), dd = keyD;
+                const DFloat4 c5 = lds.camera[5], c6 = lds.camera[6];
+                const int imgW = __builtin_bit_cast(int, c6.z), imgH = __builtin_bit_cast(int, c6.w);
+                const float curPixX = spx * c5.x, curPixY = (imgH - spy) * c5.y;
+                uint32_t a = (uint32_t)(spy * imgW + spx) ^ 0x61707865u, c = __builtin_bit_cast(uint32_t, c6.x) ^ ((uint32_t)pass >> 16), dd = __builtin_bit_cast(uint32_t, c6.y);
                 uint32_t b = ((uint32_t)(sampleY * n + sampleX) | ((uint32_t)pass << 16)) ^ 0x3320646eu;
                 KAJO_QUARTER_ROUND(a, b, c, dd);
                 KAJO_QUARTER_ROUND(a, b, c, dd);
@@ -1048,11 +1066,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 rngStep(rng);
                 float offX = unitBits((uint32_t)rng.lo);
                 float offY = unitBits((uint32_t)(rng.lo >> 32));
-                float sx = curPixX + sampleX * args.sampleWidth + offX * args.sampleWidth;
-                float sy = curPixY + sampleY * args.sampleHeight + offY * args.sampleHeight;
-                F3 dir = p1 + dp2 * sx + dp3 * sy - origin;
+                float sx = curPixX + sampleX * c5.z + offX * c5.z;
+                float sy = curPixY + sampleY * c5.w + offY * c5.w;
+                const DFloat4 c0 = lds.camera[0], c1 = lds.camera[1], c2 = lds.camera[2], c3 = lds.camera[3];
+                const F3 camOrigin = f3(c3.x, c3.y, c3.z);
+                F3 dir = f3(c0.x, c0.y, c0.z) + f3(c1.x, c1.y, c1.z) * sx + f3(c2.x, c2.y, c2.z) * sy - camOrigin;
                 d = normalize(dir);
-                O = origin;
+                O = camOrigin;
                 L = f3(0.0f, 0.0f, 0.0f);
                 T = f3(1.0f, 1.0f, 1.0f);
                 depth = 0;
@@ -1124,7 +1144,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 pendBsdf = false;
             }
             if (hit.id == 0) { // Shader.cpp:116-117
-                L = L + T * background;
+                const DFloat4 bg = lds.camera[4];
+                L = L + T * f3(bg.x, bg.y, bg.z);
                 pathDone = true;
             } else {
                 if (counting)
@@ -1214,20 +1235,28 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // Lights whose sample is discarded whatever it is -- the ideal reflector asks for none (its pdf toward any
                 // given direction is 0, BSDF.cpp:93-96), and a light that lies wholly below the vertex's horizon has
                 // max(0, n.l) = 0 for every point of it -- only draw their random number (Light.cpp:39-41: one draw per
-                // sample), in a loop of its own: the full sampling code below then runs for lights that can count.
-                for (; lightK < sc.nLights; lightK++) {
-                    const int sk = lds.light[lightK];
-                    if (np + 1 + sk == vId) // a light does not sample itself (and draws nothing)
-                        continue;
-                    const DSphereCold& lk = lds.lightCold[lightK];
-                    const F3 toC = f3(lk.cx - vP.x, lk.cy - vP.y, lk.cz - vP.z);
-                    const bool below = dot(vN, toC) < -(1.001f * lk.radius + 1e-6f * (__builtin_fabsf(toC.x) + __builtin_fabsf(toC.y) + __builtin_fabsf(toC.z)));
-                    if (!(vKind == 2 || below))
+                // sample), in a loop of its own: the full sampling code below then runs for lights that can count. Scenes
+                // of many lights only (16 lights: +6 % FAST, +25 % STRICT); with one light the test is pure overhead (-4.6 %).
+                if (!COLD_LDS && sc.nLights >= 4) { // (large-scene kernels only: in the small-scene loop the extra code costs 5 % by itself)
+                    for (; lightK < sc.nLights; lightK++) {
+                        const int sk = lds.light[lightK];
+                        if (np + 1 + sk == vId) // a light does not sample itself (and draws nothing)
+                            continue;
+                        const DSphereCold& lk = lds.lightCold[lightK];
+                        const F3 toC = f3(lk.cx - vP.x, lk.cy - vP.y, lk.cz - vP.z);
+                        const bool below = dot(vN, toC) < -(1.001f * lk.radius + 1e-6f * (__builtin_fabsf(toC.x) + __builtin_fabsf(toC.y) + __builtin_fabsf(toC.z)));
+                        if (!(vKind == 2 || below))
+                            break;
+                        rngStep(rng);
+                    }
+                    if (lightK >= sc.nLights)
                         break;
-                    rngStep(rng);
                 }
-                if (lightK >= sc.nLights)
-                    break;
+                const int si = lds.light[lightK];
+                if (np + 1 + si == vId) { // a light does not sample itself
+                    lightK++;
+                    continue;
+                }
                 const DSphereCold& lc = lds.lightCold[lightK];
                 float pl;
                 // written straight into the ray: a discarded sample leaves d and O to the next light or to the BSDF sample

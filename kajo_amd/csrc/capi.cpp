@@ -428,6 +428,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         return fail(KAJO_E_INVALID, "KAJO_STASH_DEPTH and KAJO_RING_SLOTS must be powers of two");
     }
     size_t gridBytes = 0;
+    const size_t gridHeaderBytes = st.gridEnabled ? 4 * 16 : 0; // always in LDS (integrator.inc.hip gridWalk)
     if (st.gridEnabled) {
         gridBytes = ((st.gridCellStart.size() * sizeof(uint32_t) + st.gridItems.size() * sizeof(uint16_t)) + 15) & ~(size_t)15;
         // The DDA reads a cell record and an item per step, each a dependent load: ~64 cycles from LDS, ~500 from L2. But the
@@ -445,7 +446,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
             if (window > wanted)
                 continue;
             h->stealWindow = window;
-            if (hotBytes + gridBytes + 4 * h->perWaveBytes(true) <= gridLimit) {
+            if (hotBytes + gridHeaderBytes + gridBytes + 4 * h->perWaveBytes(true) <= gridLimit) {
                 v.grid.inLds = 1;
                 break;
             }
@@ -455,9 +456,9 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
             gridBytes = 0;
         }
     }
-    h->hotBytes = hotBytes + gridBytes; // what the big-scene staging (and the known-answer kernels) put in LDS
+    h->hotBytes = hotBytes + gridHeaderBytes + gridBytes; // what the big-scene staging (and the known-answer kernels) put in LDS
     h->coldInLds = !big;
-    h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0) + gridBytes;
+    h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0) + gridHeaderBytes + gridBytes;
     // every workgroup stages its own LDS copy of the scene: single-wave groups only while that copy is small
     h->wavesPerBlock = h->ldsBytes <= 6 * 1024 ? 1 : 4;
     if (const char* e = std::getenv("KAJO_WAVES_PER_BLOCK")) { // tuning knob: 1, 2 or 4

@@ -175,6 +175,7 @@ struct LdsScene
     const DFloat4* camera;         // [7] p1, p2 - p1, p3 - p1, origin (Renderer.cpp:29-34), background, the pixel / sample sizes of
                                    // Renderer.cpp:39-42, stream key words + W + H: read where a camera ray is formed /
                                    // a ray escapes, instead of fifteen scalar registers held through the whole loop (the loop spills SGPRs)
+    const DFloat4* gridHeader;     // [4] (bmin, dim.x), (bmax, dim.y), (cell, dim.z), (1 / cell, -): LDS, read at the start of a walk
     const uint32_t* gridCellStart; // LDS copy when it fits (DGrid.inLds), else the global arrays
     const uint16_t* gridItems;
 };
@@ -251,7 +252,20 @@ KDEV bool sphereCandidate(const DSceneView& sc, const LdsScene& lds, int i, F3 O
 // (Raytracer.cpp:115 rejects only ts > max), so a sphere ties over a plane and over a lower-index sphere.
 KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float aT, float iaT, float& tMax, int& best, float& bestT0)
 {
-    const DGrid& g = sc.grid;
+    // the grid's header from LDS into vector registers for the duration of the walk (held in scalar registers through the
+    // whole render loop it made the large-scene kernels spill them by the dozen)
+    struct
+    {
+        float bmin[3], bmax[3], cell[3], invCell[3];
+        int dim[3];
+    } g;
+    {
+        const DFloat4 h0 = lds.gridHeader[0], h1 = lds.gridHeader[1], h2 = lds.gridHeader[2], h3 = lds.gridHeader[3];
+        g.bmin[0] = h0.x, g.bmin[1] = h0.y, g.bmin[2] = h0.z, g.dim[0] = __builtin_bit_cast(int, h0.w);
+        g.bmax[0] = h1.x, g.bmax[1] = h1.y, g.bmax[2] = h1.z, g.dim[1] = __builtin_bit_cast(int, h1.w);
+        g.cell[0] = h2.x, g.cell[1] = h2.y, g.cell[2] = h2.z, g.dim[2] = __builtin_bit_cast(int, h2.w);
+        g.invCell[0] = h3.x, g.invCell[1] = h3.y, g.invCell[2] = h3.z;
+    }
     const int np = sc.nPlanes;
     const float inf = __builtin_inff();
     const float ix_ = 1.0f / d.x, iy_ = 1.0f / d.y, iz_ = 1.0f / d.z;
@@ -748,7 +762,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     const int np = sc.nPlanes, ns = sc.nSpheres;
     // layout: [planeRow np x16][sphereHot nHot x16]{[planeFrame 3np x16][sphereCold ns x64]
     //         [material (np+ns) x96]}[planeDet np x4][sphereHotOffset ns x4][light nL x4] (pad to 16)
-    //         [lightCold nL x64][lightEmission nL x16][camera 7 x16]{[grid cell starts][grid items]}
+    //         [lightCold nL x64][lightEmission nL x16][camera 7 x16]{[grid header 4 x16][grid cell starts][grid items]}
     DFloat4* ldsPlaneRow = reinterpret_cast<DFloat4*>(ldsRaw);
     DFloat4* ldsSphereHot = ldsPlaneRow + np;
     DFloat4* cursor = ldsSphereHot + sc.nSphereHot;
@@ -808,9 +822,18 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     lds.lightEmission = le4;
     lds.gridCellStart = sc.grid.cellStart;
     lds.gridItems = sc.grid.items;
+    DFloat4* gh = cam4 + 7;
+    lds.gridHeader = gh;
+    if (!COLD_LDS && sc.grid.enabled && threadIdx.x == 0) {
+        const DGrid& g = sc.grid;
+        gh[0] = DFloat4{g.bmin[0], g.bmin[1], g.bmin[2], __builtin_bit_cast(float, g.dim[0])};
+        gh[1] = DFloat4{g.bmax[0], g.bmax[1], g.bmax[2], __builtin_bit_cast(float, g.dim[1])};
+        gh[2] = DFloat4{g.cell[0], g.cell[1], g.cell[2], __builtin_bit_cast(float, g.dim[2])};
+        gh[3] = DFloat4{g.invCell[0], g.invCell[1], g.invCell[2], 0.0f};
+    }
     if (!COLD_LDS && sc.grid.enabled && sc.grid.inLds) {
         // the DDA reads two cell offsets per step: from LDS that is ~64 cycles, from L2 ~500
-        uint32_t* cs = reinterpret_cast<uint32_t*>(cam4 + 7);
+        uint32_t* cs = reinterpret_cast<uint32_t*>(gh + 4);
         uint16_t* it = reinterpret_cast<uint16_t*>(cs + sc.grid.nCells + 1);
         for (int i = threadIdx.x; i <= sc.grid.nCells; i += blockDim.x)
             cs[i] = sc.grid.cellStart[i];

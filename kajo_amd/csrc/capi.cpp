@@ -380,7 +380,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     // cold records too while the total stays small enough for four workgroups per CU (160 KiB / 4).
     // (integrator.inc.hip stageToLds: the 4-byte arrays are padded to a 16-byte boundary before the light records)
     const size_t hotBytes = (size_t)v.nPlanes * 16 + (size_t)v.nSphereHot * 16 +
-                            ((((size_t)v.nPlanes + v.nSpheres + v.nLights) * 4 + 15) & ~(size_t)15) + (size_t)v.nLights * (64 + 16) + 7 * 16;
+                            ((((size_t)v.nPlanes + (v.allTranslated ? 0 : v.nSpheres) + v.nLights) * 4 + 15) & ~(size_t)15) + (size_t)v.nLights * (64 + 16) + 7 * 16;
     const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * sizeof(DMaterial);
     // What every wave adds to the scene copy (render_args.h): the mailbox of taken-over passes (and, in the deferred-shading
     // experiment, the ring of completed paths and the stash of parked vertices). Every size is a tuning knob (KAJO_STEAL_WINDOW;

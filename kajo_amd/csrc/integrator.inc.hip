@@ -789,10 +789,11 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     }
     float* ldsPlaneDet = reinterpret_cast<float*>(cursor);
     uint32_t* ldsSphereOff = reinterpret_cast<uint32_t*>(ldsPlaneDet + np);
-    int32_t* ldsLight = reinterpret_cast<int32_t*>(ldsSphereOff + ns);
+    const int nOff = sc.allTranslated ? 0 : ns; // (every sphere a (centre, radius) record: its offset is its index, nothing to look up)
+    int32_t* ldsLight = reinterpret_cast<int32_t*>(ldsSphereOff + nOff);
     for (int i = threadIdx.x; i < np; i += blockDim.x)
         ldsPlaneDet[i] = sc.planeDet[i];
-    for (int i = threadIdx.x; i < ns; i += blockDim.x)
+    for (int i = threadIdx.x; i < nOff; i += blockDim.x)
         ldsSphereOff[i] = sc.sphereHotOffset[i];
     for (int i = threadIdx.x; i < sc.nLights; i += blockDim.x)
         ldsLight[i] = sc.light[i];
@@ -800,7 +801,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     lds.sphereHotOffset = ldsSphereOff;
     lds.light = ldsLight;
     // the lights' records, by light index: [lightCold nL x64][lightEmission nL x16], 16-byte aligned behind the 4-byte arrays
-    const uintptr_t words = (uintptr_t)(np + ns + sc.nLights);
+    const uintptr_t words = (uintptr_t)(np + nOff + sc.nLights);
     DFloat4* lc4 = reinterpret_cast<DFloat4*>(ldsPlaneDet + ((words + 3u) & ~(uintptr_t)3u));
     DFloat4* le4 = lc4 + 4 * sc.nLights;
     for (int i = threadIdx.x; i < 4 * sc.nLights; i += blockDim.x)

@@ -311,7 +311,7 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
                 const DFloat4 s = lds.sphereHot[i];
                 F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
                 float h = dot(d, o);
-                float c = dot(o, o) - s.w;
+                float c = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, __builtin_fmaf(o.z, o.z, -s.w)));
                 float sq = ksqrt(h * h - aT * c);
                 const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
                 const uint32_t kth = klo < khi ? klo : khi;
@@ -375,7 +375,7 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
         for (int i = 0; i < np; i++) {
             const DFloat4 r = lds.planeRow[i];
             float denom = r.x * d.x + r.y * d.y + r.z * d.z;
-            float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w;
+            float oy = __builtin_fmaf(r.x, O.x, __builtin_fmaf(r.y, O.y, __builtin_fmaf(r.z, O.z, r.w))); // (three FMAs: the offset starts the chain)
             // (+ 0.0f: an origin exactly ON the plane gives t = -0.0 for one sign of denom, which the reference accepts --
             // `t < 0` is false, Raytracer.cpp:85-86,115 -- while its bit pattern would sort above +inf; x + (+0) turns -0
             // into +0 and leaves every other value as it is, and rides on the multiply as one FMA)
@@ -435,7 +435,7 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
             const DFloat4 s = lds.sphereHot[i];
             F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
             float h = dot(d, o);
-            float c = dot(o, o) - s.w;
+            float c = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, __builtin_fmaf(o.z, o.z, -s.w)));
             float discr = h * h - aT * c;
             float sq = ksqrt(discr);
             const uint32_t klo = __builtin_bit_cast(uint32_t, -h - sq), khi = __builtin_bit_cast(uint32_t, sq - h);

@@ -276,3 +276,16 @@ def test_sample_splitting_over_waves_is_bit_invariant(O, scenes, S, ppl, passes)
     want = O.create(sc, 1).render(W, H, S=S, passes=passes, seed=0o715517, depth_limit=8)
     with HipRenderer(sc, W, H, spp=S, strict=True, passes_per_launch=ppl) as r:
         assert bits_equal(r.render(passes).radiance(), want)
+
+
+@pytest.mark.parametrize("thr", [1, 8, 40, 64])
+def test_strict_holding_threshold_does_not_change_a_bit(O, scenes, thr, monkeypatch):
+    """STRICT loop: the light / BSDF sampling blocks run when KAJO_THR_L lanes want them or one has waited a trip
+    (integrator.inc.hip MODE_HOLD; default 24). Whatever the threshold -- every trip, rarely, never without a wait -- every
+    path takes the same decisions and every sum forms in the same order: the oracle bit for bit, 1 and 3 lights."""
+    monkeypatch.setenv("KAJO_THR_L", str(thr))
+    for key, W, H, passes in (("spheres_a169", 96, 54, 3), ("caustics_a169", 80, 45, 2)):
+        sc = scenes[key]
+        want = O.create(sc, 1).render(W, H, S=32, passes=passes, seed=0o715517, depth_limit=8)
+        with HipRenderer(sc, W, H, strict=True, passes_per_launch=2) as r:
+            assert bits_equal(r.render(passes).radiance(), want), (key, thr)

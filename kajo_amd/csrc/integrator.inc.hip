@@ -315,10 +315,12 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
                 float sq = ksqrt(h * h - aT * c);
                 const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
                 const uint32_t kth = klo < khi ? klo : khi;
-                const int id = np + 1 + i;
-                const bool ok = kth < kMax || (kth == kMax && id > best && kth <= 0x7f800000u);
+                // (a sphere met again in a later cell returns the distance it already holds: no change either way. Two
+                // DIFFERENT objects at a bit-identical distance would go to the later one in the every-object walk and to the
+                // first one here; FAST accepts that for three instructions less per test.)
+                const bool ok = kth < kMax;
                 kMax = ok ? kth : kMax;
-                best = ok ? id : best;
+                best = ok ? np + 1 + i : best;
             }
             tMax = __builtin_bit_cast(float, kMax);
             bestT0 = tMax;

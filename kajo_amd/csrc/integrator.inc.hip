@@ -176,8 +176,12 @@ struct LdsScene
                                    // Renderer.cpp:39-42, stream key words + W + H: read where a camera ray is formed /
                                    // a ray escapes, instead of fifteen scalar registers held through the whole loop (the loop spills SGPRs)
     const DFloat4* gridHeader;     // [4] (bmin, dim.x), (bmax, dim.y), (cell, dim.z), (1 / cell, -): LDS, read at the start of a walk
-    const uint32_t* gridCellStart; // LDS copy when it fits (DGrid.inLds), else the global arrays
-    const uint16_t* gridItems;
+    // The grid's cell lists, as staged into LDS when they fit (DGrid.inLds; else they are read from sc.grid's global arrays).
+    // The two homes are kept in SEPARATE pointers and the walk is instantiated once per home: a pointer that may be either
+    // compiles to FLAT loads with a full `s_waitcnt vmcnt(0) lgkmcnt(0)` behind each -- which is what round 2's walk paid for
+    // every cell record and every item (profiles/r03_c5_notes.txt).
+    const uint32_t* gridCellStartLds;
+    const uint16_t* gridItemsLds;
 };
 
 // One sphere of Raytracer.cpp:21-72 up to (not including) processIntersection: returns false when the
@@ -250,7 +254,8 @@ KDEV bool sphereCandidate(const DSceneView& sc, const LdsScene& lds, int i, F3 O
 // Large scenes: visit only the spheres registered in the grid cells the ray crosses, front to back.
 // Acceptance reproduces the brute-force walk: closest ts wins; among equal ts the later object wins
 // (Raytracer.cpp:115 rejects only ts > max), so a sphere ties over a plane and over a lower-index sphere.
-KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float aT, float iaT, float& tMax, int& best, float& bestT0)
+KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* gridCellStart, const uint16_t* gridItems, F3 O, F3 d, float aT,
+                     float iaT, float& tMax, int& best, float& bestT0)
 {
     // the grid's header from LDS into vector registers for the duration of the walk (held in scalar registers through the
     // whole render loop it made the large-scene kernels spill them by the dozen)
@@ -299,15 +304,15 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
     const int strideX = sx, strideY = sy * g.dim[0], strideZ = sz * g.dim[0] * g.dim[1];
     int leftX = sx > 0 ? g.dim[0] - 1 - cx : cx, leftY = sy > 0 ? g.dim[1] - 1 - cy : cy, leftZ = sz > 0 ? g.dim[2] - 1 - cz : cz;
     for (int guard = g.dim[0] + g.dim[1] + g.dim[2] + 3; guard > 0; guard--) {
-        const uint32_t k0 = lds.gridCellStart[cell];
-        const uint32_t e = lds.gridCellStart[cell + 1];
+        const uint32_t k0 = gridCellStart[cell];
+        const uint32_t e = gridCellStart[cell + 1];
 #if !KAJO_STRICT
         if (sc.allTranslated) {
             // (centre, radius) spheres with the bookkeeping of the brute-force walk: the smaller non-negative root is
             // the smaller bit pattern, "exists, not behind, closer" one unsigned compare (plus the tie rule)
             uint32_t kMax = __builtin_bit_cast(uint32_t, tMax);
             for (uint32_t k = k0; k < e; k++) {
-                const int i = (int)lds.gridItems[k];
+                const int i = (int)gridItems[k];
                 const DFloat4 s = lds.sphereHot[i];
                 F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
                 float h = dot(d, o);
@@ -327,7 +332,7 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
         } else
 #endif
         for (uint32_t k = k0; k < e; k++) {
-            const int i = (int)lds.gridItems[k];
+            const int i = (int)gridItems[k];
             float ts, th;
             const bool valid = sphereCandidate(sc, lds, i, O, d, aT, iaT, ts, th);
             const int id = np + 1 + i;
@@ -351,6 +356,21 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
         ny += stepY ? dy : 0.0f;
         nz += (stepX || stepY) ? 0.0f : dz;
     }
+}
+
+KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float aT, float iaT, float& tMax, int& best, float& bestT0)
+{
+#if KAJO_STRICT
+    // (one instance over a pointer of either home: the second instance costs the STRICT large-scene kernel 20 more spilled
+    // registers than its typed loads win back)
+    gridWalkIn(sc, lds, sc.grid.inLds ? lds.gridCellStartLds : sc.grid.cellStart, sc.grid.inLds ? lds.gridItemsLds : sc.grid.items, O, d, aT, iaT, tMax,
+               best, bestT0);
+#else
+    if (sc.grid.inLds) // (wave-uniform) LDS reads
+        gridWalkIn(sc, lds, lds.gridCellStartLds, lds.gridItemsLds, O, d, aT, iaT, tMax, best, bestT0);
+    else // global loads
+        gridWalkIn(sc, lds, sc.grid.cellStart, sc.grid.items, O, d, aT, iaT, tMax, best, bestT0);
+#endif
 }
 
 template <bool GRID>
@@ -823,8 +843,6 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     lds.camera = cam4; // (cam4[5], cam4[6] are the launch's, written by renderBody)
     lds.lightCold = reinterpret_cast<const DSphereCold*>(lc4);
     lds.lightEmission = le4;
-    lds.gridCellStart = sc.grid.cellStart;
-    lds.gridItems = sc.grid.items;
     DFloat4* gh = cam4 + 7;
     lds.gridHeader = gh;
     if (!COLD_LDS && sc.grid.enabled && threadIdx.x == 0) {
@@ -834,16 +852,16 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
         gh[2] = DFloat4{g.cell[0], g.cell[1], g.cell[2], __builtin_bit_cast(float, g.dim[2])};
         gh[3] = DFloat4{g.invCell[0], g.invCell[1], g.invCell[2], 0.0f};
     }
+    // the cell lists behind the header, when they fit (the pointers are formed either way; they are followed only if inLds)
+    uint32_t* cs = reinterpret_cast<uint32_t*>(gh + 4);
+    uint16_t* it = reinterpret_cast<uint16_t*>(cs + sc.grid.nCells + 1);
+    lds.gridCellStartLds = cs;
+    lds.gridItemsLds = it;
     if (!COLD_LDS && sc.grid.enabled && sc.grid.inLds) {
-        // the DDA reads two cell offsets per step: from LDS that is ~64 cycles, from L2 ~500
-        uint32_t* cs = reinterpret_cast<uint32_t*>(gh + 4);
-        uint16_t* it = reinterpret_cast<uint16_t*>(cs + sc.grid.nCells + 1);
         for (int i = threadIdx.x; i <= sc.grid.nCells; i += blockDim.x)
             cs[i] = sc.grid.cellStart[i];
         for (int i = threadIdx.x; i < sc.grid.nItems; i += blockDim.x)
             it[i] = sc.grid.items[i];
-        lds.gridCellStart = cs;
-        lds.gridItems = it;
     }
     __syncthreads();
     return lds;

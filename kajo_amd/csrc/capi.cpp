@@ -420,7 +420,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     } else {
         // STRICT loop (integrator.inc.hip MODE_HOLD): lanes that must want the light / BSDF blocks before they run without any
         // lane having waited; 1 = every trip. Large scenes run them every trip (16 lights: most lanes are in them anyway).
-        h->thrL = (h->strict() && !big) ? 24 : 1;
+        h->thrL = (h->strict() && !big) ? 28 : 1;
     }
     envInt("KAJO_THR_L", 1, 65, h->thrL);
     if (h->deferred && (!pow2(h->stashDepth) || !pow2(h->ringSlots))) {

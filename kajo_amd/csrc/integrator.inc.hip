@@ -415,15 +415,10 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
         const float det = lds.planeDet[i];
         float denom = r.x * d.x + r.y * d.y + r.z * d.z;
         float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w * 1.0f;
-#if KAJO_STRICT
-        // The correctly rounded division is a third of this test. A ray that is parallel to the plane, or that has the plane
-        // behind it (t = -oy / denom negative: oy and denom of one sign, far enough from underflow that the quotient cannot
-        // round to -0), is rejected whatever t is: a wave whose rays are all of that kind skips the division.
-        const bool behind = ((__builtin_bit_cast(uint32_t, oy) ^ __builtin_bit_cast(uint32_t, denom)) >> 31) == 0u &&
-                            __builtin_fabsf(oy) > 0x1p-60f && __builtin_fabsf(denom) < 0x1p60f;
-        if (__builtin_amdgcn_ballot_w64(!(__builtin_fabsf(denom) < kFltEpsilon) && !behind) == 0ull)
-            continue;
-#endif
+        // (Round 2 skipped the correctly rounded division for waves whose rays all have the plane behind them or parallel. The
+        // test -- ten instructions per plane, and a scalar branch that keeps the loop from being unrolled -- cost more than the
+        // division it saved on all but the first camera rays: without it STRICT runs 6.4 % faster. The spheres' skip, one
+        // ballot on `discriminant < 0`, stays: removing it loses 6 %.)
         float t = kdiv(-oy, denom);
         float ts = t * det;
         bool ok = !(__builtin_fabsf(denom) < kFltEpsilon) && !(t < 0.0f) && !(ts > tMax || ts < 0.0f);
@@ -1258,7 +1253,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         // STRICT: the light / BSDF sampling blocks are 40 % of a trip's instructions (binary32 sin/cos/asin series, IEEE
         // divisions) and run with a quarter of the lanes. They run in this trip if at least thrL lanes want them, or if some
         // lane has waited a trip already (no vertex waits twice); lanes that want them in a trip without them sit the next
-        // traversal out. Measured (profiles/r03_hold_sweep.txt): thrL = 24 is +7.5 % on configs[1]; FAST, whose blocks are a
+        // traversal out. Measured (profiles/r03_hold_sweep.txt): thrL = 24-32 is +7.5 % on configs[1]; FAST, whose blocks are a
         // third as long, gains nothing (and pays 2 % for the bookkeeping), so its loop runs them in every trip.
         const unsigned long long wantL = __ballot(sampleNext);
         const bool runL = __builtin_popcountll(wantL) >= args.thrL || __ballot(mode == MODE_HOLD) != 0ull;

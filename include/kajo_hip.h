@@ -69,7 +69,7 @@ extern "C" {
 typedef struct KajoParams {
     int32_t samplesPerPass; /* S: nominal samples per pixel per pass (reference: 32, Renderer.cpp:21);
                                n = floor(sqrt(S)) strata per axis are traced, the sum is divided by S */
-    int32_t depthLimit;     /* reference: 8 (Shader.cpp:24) */
+    int32_t depthLimit;     /* reference: 8 (Shader.cpp:24); 0 .. 1000 */
     uint64_t seed;          /* stream seed (reference constant 0715517 = 236367, Random.h:43) */
     uint32_t flags;         /* KAJO_FLAG_* */
     int32_t device;         /* HIP device ordinal */

@@ -418,9 +418,9 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         envInt("KAJO_RING_SLOTS", 1, 8, h->ringSlots);
         envInt("KAJO_THR_STALL", 1, 65, h->thrStall);
     } else {
-        // STRICT loop (integrator.inc.hip MODE_HOLD): lanes that must want the light / BSDF blocks before they run without any
-        // lane having waited; 1 = every trip. Large scenes run them every trip (16 lights: most lanes are in them anyway).
-        h->thrL = (h->strict() && !big) ? 28 : 1;
+        // integrator.inc.hip MODE_HOLD: lanes that must want the light / BSDF blocks before they run without any lane having
+        // waited a trip; 1 = every trip. Large scenes run them every trip (16 lights: most lanes are in them anyway).
+        h->thrL = big ? 1 : (h->strict() ? 28 : 20);
     }
     envInt("KAJO_THR_L", 1, 65, h->thrL);
     if (h->deferred && (!pow2(h->stashDepth) || !pow2(h->ringSlots))) {
@@ -643,6 +643,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             b.sampleChunks = (int32_t)chunks;
             const unsigned waves = (unsigned)now * chunks;
             h->fillWaveLds(b, a.mailboxOffset + (size_t)now * a.n * a.n * 64 * 16, false); // behind the [pass][sample][pixel] table
+            b.thrL = 1; // (short waves: holding a vertex only lengthens their tail -- configs[0] 18.9 against 16.5 G paths/s)
             const size_t ldsSplit = b.perWaveOffset + (size_t)waves * b.perWaveBytes;
             le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * waves, ldsSplit, h->stream)
                                           : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * waves, ldsSplit, h->stream));
@@ -651,6 +652,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             b.blockOrder = nullptr; // one round or two: the launch order does not matter
             b.waveTrips = nullptr;
             h->fillWaveLds(b, a.mailboxOffset + (size_t)now * 64 * 16, false); // behind the [pass][pixel] term table
+            b.thrL = 1; // (as above: 1-3 % on frames below 720p)
             const size_t ldsSplit = b.perWaveOffset + (size_t)split * b.perWaveBytes;
             le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream)
                                           : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream));

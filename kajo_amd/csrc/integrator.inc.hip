@@ -1141,7 +1141,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             ctrSlots += 64;
         }
 
-        bool sampleNext = KAJO_STRICT && mode == MODE_HOLD; // continue with the light loop / BSDF sampling of vertex v*
+        bool sampleNext = mode == MODE_HOLD; // continue with the light loop / BSDF sampling of vertex v*
         bool pathDone = false;
         KAJO_PROF(1, mode == MODE_EXTEND && pendBsdf && hit.id > np);
         KAJO_PROF(2, mode == MODE_EXTEND && hit.id != 0);
@@ -1249,18 +1249,17 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
 
         KAJO_STAMP(2); // vertex / shadow-result block
-#if KAJO_STRICT
-        // STRICT: the light / BSDF sampling blocks are 40 % of a trip's instructions (binary32 sin/cos/asin series, IEEE
+        // The light / BSDF sampling blocks are a third of a trip's instructions (STRICT: 40 %, binary32 sin/cos/asin series, IEEE
         // divisions) and run with a quarter of the lanes. They run in this trip if at least thrL lanes want them, or if some
-        // lane has waited a trip already (no vertex waits twice); lanes that want them in a trip without them sit the next
-        // traversal out. Measured (profiles/r03_hold_sweep.txt): thrL = 24-32 is +7.5 % on configs[1]; FAST, whose blocks are a
-        // third as long, gains nothing (and pays 2 % for the bookkeeping), so its loop runs them in every trip.
+        // lane has waited a trip already (no vertex waits twice); lanes that want them in a trip without them keep their
+        // vertex in their registers and sit the next traversal out. thrL = 1: every trip (round 2's schedule; large scenes).
+        // Measured (profiles/r03_hold_sweep.txt): STRICT +7.5 % at 24-32 lanes; FAST nothing while its loop spilled scalar
+        // registers (the two ballots cost what the blocks saved), +2.4 % at 20 lanes since it does not.
         const unsigned long long wantL = __ballot(sampleNext);
         const bool runL = __builtin_popcountll(wantL) >= args.thrL || __ballot(mode == MODE_HOLD) != 0ull;
         if (sampleNext && !runL)
             mode = MODE_HOLD;
         sampleNext = sampleNext && runL;
-#endif
         KAJO_PROF(5, sampleNext);
         if (sampleNext) {
             const DFloat4* vq = reinterpret_cast<const DFloat4*>(lds.material + (vId - 1));

@@ -51,10 +51,13 @@ WORKLOADS = {
     "c2": (1920, 1080, 16, 16, "BASELINE configs[1]"),
     "c3": (3840, 2160, 64, 64, "BASELINE configs[2]"),
 }
-PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r03_counters.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc runs
+PROFILE_COUNTERS = os.path.join(ROOT, "profiles", "r04_counters.json")  # written by tools/pmc_summary.py from rocprofv3 --pmc runs
 KERNEL_SOURCES = ["kajo_amd/csrc/integrator.inc.hip", "kajo_amd/csrc/kernel_fast.hip", "kajo_amd/csrc/kernel_strict.hip",
                   "kajo_amd/csrc/launch.inc.hip", "kajo_amd/csrc/render_args.h", "kajo_amd/csrc/device_scene.h",
-                  "kajo_amd/csrc/Makefile", "include/kajo_stream.h", "include/kajo_strictmath.h"]
+                  "kajo_amd/csrc/Makefile", "include/kajo_stream.h", "include/kajo_strictmath.h",
+                  # launch shaping (hold thresholds, steal window, split / sample-chunk selection, waves per block; grid and
+                  # material records): they change instruction counts and lane utilisation as the kernel text does
+                  "kajo_amd/csrc/capi.cpp", "kajo_amd/csrc/stage.cpp", "kajo_amd/csrc/tuning.h"]
 
 
 def kernel_source_hash():
@@ -397,7 +400,7 @@ def main():
                 "frac": achieved / PEAK_FP32_TFLOPS,
                 "traffic": pc["hbm_bytes_per_launch"] if pc else None,
                 "traffic_source": (pc["source"] + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE over this command, on kernels with this source hash)") if pc
-                                  else "no counters file for these kernels (tools/profile_round.sh rewrites profiles/r03_counters.json)",
+                                  else "no counters file for these kernels (tools/profile_round.sh rewrites profiles/r04_counters.json)",
                 "kernel": kernel, "kernel_ms_per_launch": kernel_ms, "launches_per_step": launches / args.steps,
                 "passes_per_launch": ppl,
                 "flops_per_path": fpp, "traversals_per_path": trav, "vertices_per_path": vert,
@@ -420,7 +423,10 @@ def main():
                        "backend": (args.backend if world > 1 else None),
                        # which library was timed (KAJO_HIP_LIB can point the binding at a diagnostic twin; never a CPU path)
                        "library": os.path.relpath(capi.LIB_PATH, ROOT), "library_version": capi.lib().kajo_hip_version().decode(),
-                       "kernel_source_hash": kernel_source_hash()},
+                       "kernel_source_hash": kernel_source_hash(),
+                       # launch-shaping knobs are compile-time constants of libkajo_hip.so (no getenv in it); a tools' twin
+                       # selected with KAJO_HIP_LIB reads them from the environment, so whatever was set is recorded
+                       "tuning_env": {k: v for k, v in sorted(os.environ.items()) if k.startswith("KAJO_") and k != "KAJO_HIP_LIB"}},
             "roofline": roof,
             "in_kernel_value": paths_per_launch / (kernel_ms * 1e-3) / 1e6 * world,
             "mtraversals_per_s": value * trav,

@@ -20,6 +20,7 @@
 
 #include "render_args.h"
 #include "stage.h"
+#include "tuning.h"
 
 // launchers defined next to their kernels (kernel_fast.hip, kernel_strict.hip, aux_kernels.hip)
 extern "C" {
@@ -27,10 +28,6 @@ int kajo_render_fast_launch(const RenderArgs*, int coldInLds, unsigned grid, uns
 int kajo_render_strict_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_fast_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_strict_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
-#ifdef KAJO_WITH_DEFERRED
-int kajo_render_fast_deferred_launch(const RenderArgs*, int kind, unsigned grid, unsigned block, size_t lds, void* stream);
-int kajo_render_strict_deferred_launch(const RenderArgs*, int kind, unsigned grid, unsigned block, size_t lds, void* stream);
-#endif
 int kajo_render_fast_set_lds(int coldInLds, size_t lds);
 int kajo_render_strict_set_lds(int coldInLds, size_t lds);
 int kajo_resolve_fast_launch(const void* frame, int count, float passes, void* dst, void* stream);
@@ -115,25 +112,14 @@ struct KajoHip
     int passesDone = 0;
     size_t ldsBytes = 0, hotBytes = 0;
     int stealWindow = 4; // render_args.h; 1 when a large scene needs the LDS for its grid
-    // parked vertices and out-of-order completion (integrator.inc.hip renderBody, render_args.h)
-    // EXPERIMENT (KAJO_FLAG_DEFERRED, experiment library only): parked vertices and out-of-order completion (deferred.inc.hip)
-    bool deferred = false;
-    int stashDepth = 0, ringSlots = 0, thrL = 0, thrStall = 0;
-    int ldsExtra = 0; // KAJO_LDS_EXTRA: unused bytes per wave, to study a launch at a lower occupancy (diagnostic)
-    size_t perWaveBytes(bool withMailbox) const
-    {
-        return (size_t)ldsExtra + (withMailbox ? (size_t)64 * stealWindow * 16 : 0) + (size_t)ringSlots * 3 * 64 * 4 + (size_t)stashDepth * 6 * 64 * 16;
-    }
+    int thrL = 1;        // integrator.inc.hip MODE_HOLD
+    int ldsExtra = 0;    // (KAJO_TUNING builds only) unused bytes per wave, to study a launch at a lower occupancy
+    size_t perWaveBytes(bool withMailbox) const { return (size_t)ldsExtra + (withMailbox ? (size_t)64 * stealWindow * 16 : 0); }
     void fillWaveLds(RenderArgs& a, size_t perWaveOffset, bool withMailbox) const
     {
         a.perWaveOffset = (uint32_t)perWaveOffset;
         a.perWaveBytes = (uint32_t)perWaveBytes(withMailbox);
-        a.ringOffset = withMailbox ? (uint32_t)(64 * stealWindow * 16) : 0u;
-        a.stashOffset = a.ringOffset + (uint32_t)(ringSlots * 3 * 64 * 4);
-        a.stashDepth = stashDepth;
-        a.ringSlots = ringSlots;
         a.thrL = thrL;
-        a.thrStall = thrStall;
     }
     int coldInLds = 1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // kernel timing
@@ -295,11 +281,9 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         return fail(KAJO_E_INVALID, "samplesPerPass must be in [1, 65535]");
     if (p.flags & KAJO_FLAG_COOP)
         return fail(KAJO_E_INVALID, "KAJO_FLAG_COOP: the cooperative-traversal experiment is not built into this library (make -C kajo_amd/csrc experiments)");
-#ifndef KAJO_WITH_DEFERRED
     if (p.flags & KAJO_FLAG_DEFERRED)
         return fail(KAJO_E_INVALID, "KAJO_FLAG_DEFERRED: the deferred-shading experiment is not built into this library (make -C kajo_amd/csrc experiments)");
-#endif
-    if (p.depthLimit < 0 || p.depthLimit > 1000) // (a parked vertex carries its depth in 10 bits; the reference's limit is 8)
+    if (p.depthLimit < 0 || p.depthLimit > 1000) // (the reference's limit is 8)
         return fail(KAJO_E_INVALID, "depthLimit must be in [0, 1000]");
     if (p.tileW < 8 || p.tileH < 8 || (p.tileW & 7) || (p.tileH & 7) || (p.tileW * p.tileH) % 256)
         return fail(KAJO_E_INVALID, "tile size must be multiples of 8 with tileW*tileH a multiple of 256");
@@ -382,51 +366,18 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     const size_t hotBytes = (size_t)v.nPlanes * 16 + (size_t)v.nSphereHot * 16 +
                             ((((size_t)v.nPlanes + (v.allTranslated ? 0 : v.nSpheres) + v.nLights) * 4 + 15) & ~(size_t)15) + (size_t)v.nLights * (64 + 16) + 7 * 16;
     const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * sizeof(DMaterial);
-    // What every wave adds to the scene copy (render_args.h): the mailbox of taken-over passes (and, in the deferred-shading
-    // experiment, the ring of completed paths and the stash of parked vertices). Every size is a tuning knob (KAJO_STEAL_WINDOW;
-    // KAJO_STASH_DEPTH, KAJO_RING_SLOTS, KAJO_THR_L, KAJO_THR_STALL), applied BEFORE the LDS budget is checked.
-    auto envInt = [](const char* name, int lo, int hi, int& v) {
-        if (const char* e = std::getenv(name)) {
-            const int x = std::atoi(e);
-            if (x >= lo && x <= hi)
-                v = x;
-        }
-    };
-    auto pow2 = [](int x) { return x > 0 && (x & (x - 1)) == 0; };
+    // What every wave adds to the scene copy (render_args.h): the mailbox of taken-over passes.
+    // The sizes below are constants of the product library. A -DKAJO_TUNING build (libkajo_hip_tune.so, tools/ only) reads
+    // overrides from the environment (tuning.h); libkajo_hip.so contains no getenv.
     const bool big = st.gridEnabled || hotBytes + coldBytes > 40 * 1024;
-    h->deferred = (p.flags & KAJO_FLAG_DEFERRED) != 0;
     h->stealWindow = 4;
-    if (h->deferred) {
-        if (big) { // the walk dominates and wants its occupancy: the light / BSDF blocks run in every trip
-            h->stashDepth = 1;
-            h->ringSlots = 1;
-            h->thrL = 1;
-            h->thrStall = 1;
-        } else {
-            h->stealWindow = 2;
-            h->stashDepth = 1;
-            h->ringSlots = 2;
-            h->thrL = 32;
-            h->thrStall = 8;
-        }
-    }
-    envInt("KAJO_STEAL_WINDOW", 1, 16, h->stealWindow);
-    envInt("KAJO_LDS_EXTRA", 0, 64 * 1024, h->ldsExtra);
+    KAJO_TUNE_INT("KAJO_STEAL_WINDOW", 1, 16, h->stealWindow);
+    KAJO_TUNE_INT("KAJO_LDS_EXTRA", 0, 64 * 1024, h->ldsExtra);
     h->ldsExtra &= ~15;
-    if (h->deferred) {
-        envInt("KAJO_STASH_DEPTH", 1, 4, h->stashDepth);
-        envInt("KAJO_RING_SLOTS", 1, 8, h->ringSlots);
-        envInt("KAJO_THR_STALL", 1, 65, h->thrStall);
-    } else {
-        // integrator.inc.hip MODE_HOLD: lanes that must want the light / BSDF blocks before they run without any lane having
-        // waited a trip; 1 = every trip. Large scenes run them every trip (16 lights: most lanes are in them anyway).
-        h->thrL = big ? 1 : (h->strict() ? 28 : 20);
-    }
-    envInt("KAJO_THR_L", 1, 65, h->thrL);
-    if (h->deferred && (!pow2(h->stashDepth) || !pow2(h->ringSlots))) {
-        destroy(h);
-        return fail(KAJO_E_INVALID, "KAJO_STASH_DEPTH and KAJO_RING_SLOTS must be powers of two");
-    }
+    // integrator.inc.hip MODE_HOLD: lanes that must want the light / BSDF blocks before they run without any lane having
+    // waited a trip; 1 = every trip. Large scenes run them every trip (16 lights: most lanes are in them anyway).
+    h->thrL = big ? 1 : (h->strict() ? 28 : 20);
+    KAJO_TUNE_INT("KAJO_THR_L", 1, 65, h->thrL);
     size_t gridBytes = 0;
     const size_t gridHeaderBytes = st.gridEnabled ? 4 * 16 : 0; // always in LDS (integrator.inc.hip gridWalk)
     if (st.gridEnabled) {
@@ -435,18 +386,15 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         // walk is latency-bound and wants its workgroups per CU (measured on the 1000-sphere scene in round 2: the grid in LDS
         // at three workgroups per CU is 12 % SLOWER than the grid in L2 at four), so the grid moves into LDS only while hot
         // records + grid + the four waves' areas stay within the limit.
-        size_t gridLimit = 40 * 1024;
-        if (const char* e = std::getenv("KAJO_GRID_LDS_LIMIT")) { // tuning knob, bytes
-            const long x = std::atol(e);
-            gridLimit = x < 0 ? 0 : (x > 160 * 1024 ? 160 * 1024 : (size_t)x);
-        }
+        int gridLimit = 40 * 1024;
+        KAJO_TUNE_INT("KAJO_GRID_LDS_LIMIT", 0, 160 * 1024, gridLimit); // bytes
         // ... with the mailboxes shrunk to a one-pass steal window if need be
         const int wanted = h->stealWindow;
         for (int window : {4, 2, 1}) {
             if (window > wanted)
                 continue;
             h->stealWindow = window;
-            if (hotBytes + gridHeaderBytes + gridBytes + 4 * h->perWaveBytes(true) <= gridLimit) {
+            if (hotBytes + gridHeaderBytes + gridBytes + 4 * h->perWaveBytes(true) <= (size_t)gridLimit) {
                 v.grid.inLds = 1;
                 break;
             }
@@ -461,15 +409,16 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0) + gridHeaderBytes + gridBytes;
     // every workgroup stages its own LDS copy of the scene: single-wave groups only while that copy is small
     h->wavesPerBlock = h->ldsBytes <= 6 * 1024 ? 1 : 4;
-    if (const char* e = std::getenv("KAJO_WAVES_PER_BLOCK")) { // tuning knob: 1, 2 or 4
-        const int w = std::atoi(e);
+    {
+        int w = 0;
+        KAJO_TUNE_INT("KAJO_WAVES_PER_BLOCK", 1, 4, w); // 1, 2 or 4
         if (w == 1 || w == 2 || w == 4)
             h->wavesPerBlock = (unsigned)w;
     }
     // the one check, with the final values: scene copy + the waves' areas must fit a CU
     if (((h->ldsBytes + 15) & ~(size_t)15) + (size_t)h->wavesPerBlock * h->perWaveBytes(true) > 160 * 1024) {
         destroy(h);
-        return fail(KAJO_E_INVALID, "scene exceeds the LDS staging limit: scene records + the waves' mailbox / ring / stash areas must fit 160 KiB");
+        return fail(KAJO_E_INVALID, "scene exceeds the LDS staging limit: scene records + the waves' mailboxes must fit 160 KiB");
     }
     // ---- tiles -----------------------------------------------------------------------------
     TileMap& m = h->map;
@@ -580,7 +529,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
     const unsigned grid = h->gridBlocks;
     a.blockOrder = h->orderValid ? h->blockOrder : nullptr;
     a.waveTrips = (h->waveTrips && !h->orderValid) ? h->waveTrips : nullptr; // measure once, on the first launch
-    // scene copy + every wave's mailbox, ring and stash
+    // scene copy + every wave's mailbox
     h->fillWaveLds(a, a.mailboxOffset, true);
     const size_t ldsTotal = a.mailboxOffset + (size_t)h->wavesPerBlock * a.perWaveBytes;
     const int perLaunch = p.passesPerLaunch > 0 ? p.passesPerLaunch : 16;
@@ -597,18 +546,17 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         // block and divide the passes of the launch (when they divide evenly); the per-pass terms meet in LDS.
         unsigned split = 1;
         const unsigned long long pixelBlocks = (unsigned long long)grid * h->wavesPerBlock;
-        if (h->coldInLds && !(p.flags & KAJO_FLAG_NO_SPLIT) && !h->deferred) {
+        if (h->coldInLds && !(p.flags & KAJO_FLAG_NO_SPLIT)) {
             // measured (tools/size_sweep.py with KAJO_SPLIT=1..16, 256x144 ... 1920x1080): frames of fewer than three
             // rounds of the 4096 wave slots run best with the largest power of two -- up to 16 waves per block, as far
             // as the passes divide -- that keeps the launch within 8 rounds: many short waves pack the tail of the
             // launch better than few long ones. From 1280x720 on the unsplit kernel is 3-8 % faster.
             while (pixelBlocks < 3 * 4096 && split < 16 && now % (int)(split * 2) == 0 && pixelBlocks * split * 2 <= 8 * 4096)
                 split *= 2;
-            if (const char* e = std::getenv("KAJO_SPLIT")) { // tuning knob
-                const int v = std::atoi(e);
-                if (v >= 1 && v <= 16 && (v & (v - 1)) == 0 && now % v == 0)
-                    split = (unsigned)v;
-            }
+            int v = 0;
+            KAJO_TUNE_INT("KAJO_SPLIT", 1, 16, v);
+            if (v >= 1 && (v & (v - 1)) == 0 && now % v == 0)
+                split = (unsigned)v;
         }
         while (split > 1 && a.mailboxOffset + (size_t)now * 64 * 16 + split * h->perWaveBytes(false) > 48 * 1024)
             split /= 2; // the table and the waves' areas would need the large-LDS opt-in: not worth it
@@ -617,7 +565,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         // per block -- and the paths' radiances meet in the table [pass][sample][pixel]. Chosen when it puts more waves on a
         // block than dividing the passes does.
         unsigned chunks = 1;
-        if (h->coldInLds && !(p.flags & KAJO_FLAG_NO_SPLIT) && !h->deferred && pixelBlocks < 3 * 4096) {
+        if (h->coldInLds && !(p.flags & KAJO_FLAG_NO_SPLIT) && pixelBlocks < 3 * 4096) {
             const unsigned nn = (unsigned)(a.n * a.n);
             // the smallest division that gives the launch one round of the chip's wave slots (measured on configs[0], 1024 blocks:
             // 4 chunks 18.0, 8 chunks 17.4, 16 chunks 15.5 G paths/s against 8.3 undivided; profiles/r03_configs.txt)
@@ -627,11 +575,11 @@ int kajo_hip_render(kajo_hip_t h, int passes)
                     if (pixelBlocks * now * q >= 4096)
                         break;
                 }
-            if (const char* e = std::getenv("KAJO_SAMPLE_CHUNKS")) { // tuning knob
-                const unsigned v = (unsigned)std::atoi(e);
-                if (v >= 1 && v <= 16 && nn % v == 0 && (unsigned)now * v <= 16 && a.mailboxOffset + (size_t)now * nn * 64 * 16 <= 48 * 1024)
-                    chunks = v;
-            }
+            int v = 0;
+            KAJO_TUNE_INT("KAJO_SAMPLE_CHUNKS", 1, 16, v); // (held to the same 48 KiB bound as the automatic choice, the waves' areas included)
+            if (v >= 1 && nn % (unsigned)v == 0 && (unsigned)now * v <= 16 &&
+                a.mailboxOffset + (size_t)now * nn * 64 * 16 + (size_t)now * v * h->perWaveBytes(false) <= 48 * 1024)
+                chunks = (unsigned)v;
             if ((unsigned)now * chunks <= split)
                 chunks = 1;
         }
@@ -656,11 +604,6 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             const size_t ldsSplit = b.perWaveOffset + (size_t)split * b.perWaveBytes;
             le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream)
                                           : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream));
-#ifdef KAJO_WITH_DEFERRED
-        } else if (h->deferred) {
-            le = (hipError_t)(h->strict() ? kajo_render_strict_deferred_launch(&a, h->coldInLds ? 0 : 1, grid, block, ldsTotal, h->stream)
-                                          : kajo_render_fast_deferred_launch(&a, h->coldInLds ? 0 : 1, grid, block, ldsTotal, h->stream));
-#endif
         } else {
             le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream)
                                           : kajo_render_fast_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream));
@@ -929,16 +872,9 @@ int kajo_hip_kat_shade(kajo_hip_t h, int n, const float* origins, const float* d
     h->fillWaveLds(a, a.mailboxOffset, false);
     const size_t ldsKat = a.mailboxOffset + 4 * (size_t)a.perWaveBytes;
     if (ldsKat > 64 * 1024)
-        return fail(KAJO_E_INVALID, "known-answer entry points are limited to scenes whose hot records fit 48 KiB of LDS");
+        return fail(KAJO_E_INVALID, "known-answer entry points are limited to scenes whose hot records and wave areas fit 64 KiB of LDS");
     const unsigned grid = (unsigned)((n + 255) / 256);
-    hipError_t le;
-#ifdef KAJO_WITH_DEFERRED
-    if (h->deferred)
-        le = (hipError_t)(h->strict() ? kajo_render_strict_deferred_launch(&a, 2, grid, 256, ldsKat, h->stream)
-                                      : kajo_render_fast_deferred_launch(&a, 2, grid, 256, ldsKat, h->stream));
-    else
-#endif
-    le = (hipError_t)(h->strict() ? kajo_kat_shade_strict_launch(&a, grid, ldsKat, h->stream)
+    hipError_t le = (hipError_t)(h->strict() ? kajo_kat_shade_strict_launch(&a, grid, ldsKat, h->stream)
                                   : kajo_kat_shade_fast_launch(&a, grid, ldsKat, h->stream));
     if (le != hipSuccess)
         return failHip(le, "kat shade launch");

@@ -1457,10 +1457,6 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_
     renderBody<false, false>(args, ldsRaw);
 }
 
-#ifdef KAJO_WITH_DEFERRED
-#include "deferred.inc.hip"
-#endif
-
 // known-answer kernels (kajo_hip_kat_shade / kajo_hip_kat_trace): the SAME device functions, fed rays
 extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KAT_SHADE_NAME(const RenderArgs args)
 {

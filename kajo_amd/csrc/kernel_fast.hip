@@ -7,9 +7,6 @@
 #define KAJO_KERNEL_NAME_BIG kajo_render_fast_big
 #define KAJO_KERNEL_NAME_SPLIT kajo_render_fast_split
 #define KAJO_KAT_SHADE_NAME kajo_kat_shade_fast
-#define KAJO_KERNEL_NAME_DEFERRED kajo_render_fast_deferred
-#define KAJO_KERNEL_NAME_DEFERRED_BIG kajo_render_fast_deferred_big
-#define KAJO_KAT_SHADE_NAME_DEFERRED kajo_kat_shade_fast_deferred
 #define KAJO_KAT_TRACE_NAME kajo_kat_trace_fast
 #define KAJO_RESOLVE_NAME kajo_resolve_fast
 #include "integrator.inc.hip"

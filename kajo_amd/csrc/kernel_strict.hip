@@ -4,9 +4,6 @@
 #define KAJO_KERNEL_NAME_BIG kajo_render_strict_big
 #define KAJO_KERNEL_NAME_SPLIT kajo_render_strict_split
 #define KAJO_KAT_SHADE_NAME kajo_kat_shade_strict
-#define KAJO_KERNEL_NAME_DEFERRED kajo_render_strict_deferred
-#define KAJO_KERNEL_NAME_DEFERRED_BIG kajo_render_strict_deferred_big
-#define KAJO_KAT_SHADE_NAME_DEFERRED kajo_kat_shade_strict_deferred
 #define KAJO_KAT_TRACE_NAME kajo_kat_trace_strict
 #define KAJO_RESOLVE_NAME kajo_resolve_strict
 #include "integrator.inc.hip"

@@ -20,29 +20,6 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _split_launch)(const RenderArgs* args,
     return (int)hipGetLastError();
 }
 
-#ifdef KAJO_WITH_DEFERRED
-// experiment build only (deferred.inc.hip): kind 0 = whole scene in LDS, 1 = cold records global, 2 = known-answer shade
-extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _deferred_launch)(const RenderArgs* args, int kind, unsigned grid, unsigned block, size_t ldsBytes, void* stream)
-{
-    static size_t highWater[3] = {0, 0, 0};
-    const void* fn = kind == 0 ? reinterpret_cast<const void*>(KAJO_KERNEL_NAME_DEFERRED)
-                               : (kind == 1 ? reinterpret_cast<const void*>(KAJO_KERNEL_NAME_DEFERRED_BIG) : reinterpret_cast<const void*>(KAJO_KAT_SHADE_NAME_DEFERRED));
-    if (ldsBytes > 48 * 1024 && ldsBytes > highWater[kind]) {
-        const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
-        if (e != hipSuccess)
-            return (int)e;
-        highWater[kind] = ldsBytes;
-    }
-    if (kind == 0)
-        hipLaunchKernelGGL(KAJO_KERNEL_NAME_DEFERRED, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
-    else if (kind == 1)
-        hipLaunchKernelGGL(KAJO_KERNEL_NAME_DEFERRED_BIG, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
-    else
-        hipLaunchKernelGGL(KAJO_KAT_SHADE_NAME_DEFERRED, dim3(grid), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), *args);
-    return (int)hipGetLastError();
-}
-#endif
-
 // Dynamic LDS above the 64 KiB default needs an explicit opt-in on the function. The attribute is state of the
 // FUNCTION, shared by every handle of the process: it is only ever raised (a later, smaller scene must not lower the
 // limit under an earlier handle's launches).

@@ -24,14 +24,9 @@ struct RenderArgs
     int32_t sampleChunks;         // SPLIT kernels: > 1 = every pass's n*n samples are divided over this many waves of the block (integrator.inc.hip)
     int32_t stealWindow;          // passes at the end of a launch an idle lane may take over (1..KAJO_STEAL_WINDOW_MAX): sizes the mailboxes
     // Per-wave LDS (integrator.inc.hip renderBody): wave w of the workgroup owns perWaveBytes at perWaveOffset + w * perWaveBytes:
-    //   [0, ringOffset)            mailbox of taken-over passes, 64 lanes x stealWindow x float4   (absent in the SPLIT kernels)
-    //   [ringOffset, stashOffset)  radiances of completed paths waiting for an older path of their lane, ringSlots x 3 x 64 floats
-    //   [stashOffset, ..)          parked vertices, stashDepth x 6 x 64 float4
-    uint32_t perWaveOffset, perWaveBytes, ringOffset, stashOffset;
-    int32_t stashDepth;           // parked vertices per lane: 1, 2 or 4
-    int32_t ringSlots;            // 1, 2, 4 or 8: a lane has at most ringSlots + 1 paths in flight
-    int32_t thrL;                 // the light/BSDF blocks run in a trip when this many lanes have a parked vertex and free registers ...
-    int32_t thrStall;             // ... or this many of them cannot start another camera path
+    // the mailbox of taken-over passes, 64 lanes x stealWindow x float4 (absent in the SPLIT kernels).
+    uint32_t perWaveOffset, perWaveBytes;
+    int32_t thrL;                 // MODE_HOLD: the light / BSDF blocks run in a trip when this many lanes want them, or one has waited a trip
     // Launch-order feedback: blocks are dispatched in blockIdx order; the host sorts them by the cost the
     // previous launch measured (longest first) so that the launch does not end on its most expensive
     // workgroups. Pure scheduling: the buffer slot of a pixel does not depend on it.

@@ -10,6 +10,7 @@
 // binary32; this file must be compiled with FP contraction off (-ffp-contract=off), because the
 // STRICT kernels are compared bit for bit with a CPU evaluation of the same expressions.
 #include "stage.h"
+#include "tuning.h"
 
 #include <cmath>
 #include <cstdlib>
@@ -213,8 +214,7 @@ void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
         vol *= ext[k];
     }
     double cellsPerSphere = 1.0; // measured on the 1000-sphere scene: 0.5 .. 2 within 10 %, finer grids lose to the cell stepping
-    if (const char* e = std::getenv("KAJO_GRID_CELLS_PER_SPHERE")) // tuning knob
-        cellsPerSphere = std::atof(e) > 0 ? std::atof(e) : cellsPerSphere;
+    KAJO_TUNE_DOUBLE("KAJO_GRID_CELLS_PER_SPHERE", cellsPerSphere);
     const double side = std::cbrt(vol / (cellsPerSphere * n));
     size_t cells = 1;
     for (int k = 0; k < 3; k++) {
@@ -243,7 +243,7 @@ void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
         for (int c = 0; c < 3; c++)
             for (int r = 0; r < 3; r++)
                 identity3 = identity3 && M.e(c, r) == (c == r ? 1.f : 0.f);
-        ball[i] = identity3 && std::getenv("KAJO_GRID_BOX_REGISTRATION") == nullptr; // (knob: register the whole box, as round 2 did)
+        ball[i] = identity3 && !KAJO_TUNE_SET("KAJO_GRID_BOX_REGISTRATION"); // (tuning builds: register the whole box, as round 2 did)
     }
     auto reaches = [&](int i, int x, int y, int z) {
         if (!ball[i])

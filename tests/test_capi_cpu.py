@@ -83,3 +83,21 @@ def test_product_never_imports_oracle():
                 if re.search(r"oracle/|koracle_|kref_|libkajo_oracle|libkajo_ref", text):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_product_library_has_no_environment_knobs():
+    """Launch-shaping constants (hold thresholds, steal window, waves per block, split selection, grid density) are compile-time
+    constants of libkajo_hip.so, as the reference's own are (renderer/cpu/Shader.cpp:23-24, Renderer.cpp:21): the library
+    neither imports getenv nor contains a knob name. The tools' twin libkajo_hip_tune.so (kajo_amd/csrc/tuning.h) does."""
+    import re
+    import subprocess
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(here, "kajo_amd", "libkajo_hip.so")
+    blob = open(lib, "rb").read()
+    names = set(re.findall(rb"KAJO_[A-Z_]{3,}", blob)) - {b"KAJO_FLAG_COOP", b"KAJO_FLAG_DEFERRED"}  # (two error messages name the refused flags)
+    assert not names, names
+    syms = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True).stdout
+    assert "getenv" not in syms
+    tune = os.path.join(here, "kajo_amd", "libkajo_hip_tune.so")
+    if os.path.exists(tune):
+        assert b"KAJO_THR_L" in open(tune, "rb").read()

@@ -8,6 +8,7 @@
 """
 import ctypes as C
 import json
+import os
 
 import numpy as np
 import pytest
@@ -278,14 +279,39 @@ def test_sample_splitting_over_waves_is_bit_invariant(O, scenes, S, ppl, passes)
         assert bits_equal(r.render(passes).radiance(), want)
 
 
-@pytest.mark.parametrize("thr", [1, 8, 40, 64])
-def test_strict_holding_threshold_does_not_change_a_bit(O, scenes, thr, monkeypatch):
-    """STRICT loop: the light / BSDF sampling blocks run when KAJO_THR_L lanes want them or one has waited a trip
-    (integrator.inc.hip MODE_HOLD; default 24). Whatever the threshold -- every trip, rarely, never without a wait -- every
-    path takes the same decisions and every sum forms in the same order: the oracle bit for bit, 1 and 3 lights."""
-    monkeypatch.setenv("KAJO_THR_L", str(thr))
-    for key, W, H, passes in (("spheres_a169", 96, 54, 3), ("caustics_a169", 80, 45, 2)):
-        sc = scenes[key]
-        want = O.create(sc, 1).render(W, H, S=32, passes=passes, seed=0o715517, depth_limit=8)
-        with HipRenderer(sc, W, H, strict=True, passes_per_launch=2) as r:
-            assert bits_equal(r.render(passes).radiance(), want), (key, thr)
+def test_strict_holding_threshold_does_not_change_a_bit():
+    """STRICT loop: the light / BSDF sampling blocks run when `thrL` lanes want them or one has waited a trip
+    (integrator.inc.hip MODE_HOLD; the product's constants are 28 STRICT / 20 FAST, 1 for large scenes: capi.cpp). Whatever
+    the threshold -- every trip, rarely, never without a wait -- every path takes the same decisions and every sum forms in
+    the same order: the oracle bit for bit, 1 and 3 lights. The threshold is a constant of libkajo_hip.so; the sweep runs in a
+    child process on the tools' twin libkajo_hip_tune.so (same kernel objects; KAJO_THR_L read by its capi.cpp, tuning.h)."""
+    import subprocess
+    import sys
+    import textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tune = os.path.join(root, "kajo_amd", "libkajo_hip_tune.so")
+    if not os.path.exists(tune):
+        pytest.skip("libkajo_hip_tune.so not built (make -C kajo_amd/csrc tune)")
+    code = textwrap.dedent("""
+        import os, sys
+        sys.path[:0] = [%r, %r]
+        import numpy as np
+        from kajo_amd import capi
+        from kajo_amd.renderer import HipRenderer
+        from kajo_amd.scene import Scene
+        from oraclelib import OracleLib
+        from test_hip_parity import bits_equal
+        assert capi.LIB_PATH.endswith("libkajo_hip_tune.so")
+        z = np.load(%r)
+        O = OracleLib("oracle")
+        for key, W, H, passes in (("spheres_a169", 96, 54, 3), ("caustics_a169", 80, 45, 2)):
+            sc = Scene.from_npz(z, key + "/", key)
+            want = O.create(sc, 1).render(W, H, S=32, passes=passes, seed=0o715517, depth_limit=8)
+            for thr in (1, 8, 40, 64):
+                os.environ["KAJO_THR_L"] = str(thr)
+                with HipRenderer(sc, W, H, strict=True, passes_per_launch=2) as r:
+                    assert bits_equal(r.render(passes).radiance(), want), (key, thr)
+        print("hold ok")
+    """) % (root, os.path.join(root, "tests"), os.path.join(root, "tests", "golden", "scenes.npz"))
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, KAJO_HIP_LIB=tune), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "hold ok" in p.stdout, p.stdout[-2000:] + p.stderr[-2000:]

@@ -1,12 +1,12 @@
 #!/bin/bash
 # The whole evidence run of a round in one `gpurun` call: bench line, `rocprofv3 --kernel-trace --stats` (FAST, STRICT), the PMC
 # passes (counters only ever with --kernel-trace, separate passes), the other BASELINE configs, block profiles.
-#   tools/profile_round.sh [round tag, default r03]
+#   tools/profile_round.sh [round tag, default r04]
 # Results under gpurun_out/<tag>prof/; copy what is to be judged into profiles/ (bench.py reads profiles/<tag>_counters.json,
 # which carries the hash of the kernel sources it was collected on: stale counters are not reported).
-# Needs the diagnostic twins: make -C kajo_amd/csrc prof experiments   (built here: the GPU box has the same toolchain)
+# Needs the diagnostic twins: make -C kajo_amd/csrc prof   (built here: the GPU box has the same toolchain)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/${R}prof
 mkdir -p $OUT
 [ -f kajo_amd/libkajo_hip_prof.so ] || make -s -C kajo_amd/csrc prof || { echo "no profile twin" >&2; exit 1; }

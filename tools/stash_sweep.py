@@ -1,4 +1,5 @@
-"""Sweep of the deferred-shading knobs (integrator.inc.hip renderBody; capi.cpp reads them when a handle is created):
+"""Sweep of the launch-shaping knobs (read by libkajo_hip_tune.so when a handle is created, kajo_amd/csrc/tuning.h; the deferred
+experiment's stash / ring knobs by libkajo_hip_exp.so):
 KAJO_STASH_DEPTH, KAJO_RING_SLOTS, KAJO_THR_L, KAJO_THR_STALL, KAJO_STEAL_WINDOW, KAJO_WAVES_PER_BLOCK.
 
   python tools/stash_sweep.py [c2|c4|c5|c1] [fast|strict] [--lib PATH ...] "D=2,R=4,L=40,S=12,W=2,B=1" ...
@@ -99,6 +100,8 @@ def main():
         if lib:
             env["KAJO_HIP_LIB"] = os.path.join(ROOT, lib) if not os.path.isabs(lib) else lib
         cfgs = configs if lib is None else [""]
+        if lib is None and any(cfgs):  # knobs are read by the tools' twin only (kajo_amd/csrc/tuning.h); the product library ignores them
+            env["KAJO_HIP_LIB"] = os.path.join(ROOT, "kajo_amd", "libkajo_hip_tune.so")
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child", workload, mode, json.dumps(cfgs)], env=env, check=False)
 
 

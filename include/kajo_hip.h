@@ -65,6 +65,8 @@ extern "C" {
                                    experiments`, refused by the product library): surviving vertices are parked in LDS and the light / BSDF
                                    sampling blocks run only in trips where enough lanes have one (deferred.inc.hip) */
 #define KAJO_FLAG_NO_SPLIT 16u  /* small frames: do not let several waves share a pixel block and divide the passes */
+#define KAJO_FLAG_NO_SHADOW_LISTS 128u /* large scenes: shadow rays walk the uniform grid as extension rays do, instead of being answered
+                                   from the lights' visibility lists inside the light loop (same results; for A/B runs and tests) */
 
 typedef struct KajoParams {
     int32_t samplesPerPass; /* S: nominal samples per pixel per pass (reference: 32, Renderer.cpp:21);
@@ -89,6 +91,8 @@ typedef struct KajoCounters {
     uint64_t laneSlots;      /* 64 * wave-iterations of the trace loop: traversals / laneSlots = lane efficiency */
     double kernelMs;         /* summed device time of the render kernels (HIP events on the handle's stream) */
     uint64_t launches;       /* render kernel launches */
+    uint64_t shadowQueries;  /* large scenes: shadow rays answered from the lights' visibility lists inside the light loop (they
+                                are not among `traversals`, which then counts camera and extension rays only) */
 } KajoCounters;
 
 typedef struct KajoHip* kajo_hip_t;
@@ -137,6 +141,14 @@ int kajo_hip_counters(kajo_hip_t h, KajoCounters* out);
    determinant per object, planes first then spheres, 17 floats each (cpu/Scene.cpp:9-13) and
    the camera basis p1, p2, p3, origin (Renderer.cpp:30-34), 12 floats. For tests. */
 int kajo_hip_stage_scene(const KajoScene* scene, float* invDet17, float* basis12);
+
+/* Host-only helper (no GPU needed), for tests: the per-light visibility lists create() stages for large scenes whose spheres
+   are all world-space balls (kajo_amd/csrc/device_scene.h DShadowLists) -- what a shadow query tests instead of walking the grid.
+   Returns the number of list items (0 = the scene gets no lists; negative = error). *binsPerAxis = n of the 6 x n x n cube-map
+   bins per light, *nLights = emissive spheres; lightSphere[nLights] their sphere indices; start[nLights * 6 n^2 + 1],
+   key[items], index[items] are filled when non-null (call once with nulls for the sizes). */
+int kajo_hip_stage_shadow_lists(const KajoScene* scene, int32_t* binsPerAxis, int32_t* nLights, int32_t* lightSphere, uint32_t* start,
+                                size_t startCapacity, float* key, uint32_t* index, size_t itemCapacity);
 
 /* Known-answer hooks: run the kernels' OWN device functions on caller-supplied rays, so that the
    vectors captured from the compiled reference (tests/golden/kat_trace.npz, kat_shade.npz) can be

@@ -27,6 +27,7 @@ KAJO_FLAG_NO_REORDER = 8
 KAJO_FLAG_NO_SPLIT = 16
 KAJO_FLAG_COOP = 32      # experiment library libkajo_hip_r02.so only
 KAJO_FLAG_DEFERRED = 64  # experiment library libkajo_hip_exp.so only
+KAJO_FLAG_NO_SHADOW_LISTS = 128
 
 # every symbol include/kajo_hip.h declares
 EXPORTS = [
@@ -34,7 +35,7 @@ EXPORTS = [
     "kajo_hip_reset", "kajo_hip_set_pass_count", "kajo_hip_resolve_argb8", "kajo_hip_read_radiance", "kajo_hip_resolve_argb8_device",
     "kajo_hip_tile_buffer", "kajo_hip_compose", "kajo_hip_set_stream", "kajo_hip_counters",
     "kajo_hip_stage_scene", "kajo_hip_last_error", "kajo_hip_version", "kajo_hip_kat_trace", "kajo_hip_kat_shade",
-    "kajo_hip_kat_strictmath",
+    "kajo_hip_kat_strictmath", "kajo_hip_stage_shadow_lists",
 ]
 
 
@@ -63,6 +64,7 @@ class KajoCounters(C.Structure):
         ("laneSlots", C.c_uint64),
         ("kernelMs", C.c_double),
         ("launches", C.c_uint64),
+        ("shadowQueries", C.c_uint64),  # (appended in round 4; the experiment libraries of earlier rounds leave it 0)
     ]
 
 
@@ -93,6 +95,8 @@ def lib():
         L.kajo_hip_counters.argtypes = [C.c_void_p, C.POINTER(KajoCounters)]
         L.kajo_hip_stage_scene.argtypes = [C.POINTER(KajoScene), C.c_void_p, C.c_void_p]
         L.kajo_hip_default_params.argtypes = [C.POINTER(KajoParams)]
+        L.kajo_hip_stage_shadow_lists.argtypes = [C.POINTER(KajoScene), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p, C.c_size_t,
+                                                  C.c_void_p, C.c_void_p, C.c_size_t]
         L.kajo_hip_kat_trace.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         L.kajo_hip_kat_shade.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.kajo_hip_kat_strictmath.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

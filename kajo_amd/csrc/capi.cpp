@@ -261,6 +261,39 @@ int kajo_hip_stage_scene(const KajoScene* scene, float* invDet17, float* basis12
     return KAJO_OK;
 }
 
+int kajo_hip_stage_shadow_lists(const KajoScene* scene, int32_t* binsPerAxis, int32_t* nLights, int32_t* lightSphere, uint32_t* start,
+                                size_t startCapacity, float* key, uint32_t* index, size_t itemCapacity)
+{
+    if (!scene || !binsPerAxis || !nLights)
+        return fail(KAJO_E_INVALID, "null argument");
+    kajo::StagedScene st;
+    kajo::stageScene(*scene, st);
+    *binsPerAxis = st.shadowEnabled ? st.shadowN : 0;
+    *nLights = (int32_t)st.light.size();
+    if (!st.shadowEnabled)
+        return 0;
+    if (lightSphere)
+        std::memcpy(lightSphere, st.light.data(), st.light.size() * sizeof(int32_t));
+    if (start) {
+        if (startCapacity < st.shadowStart.size())
+            return fail(KAJO_E_INVALID, "start array too small");
+        std::memcpy(start, st.shadowStart.data(), st.shadowStart.size() * sizeof(uint32_t));
+    }
+    if (key || index) {
+        if (itemCapacity < st.shadowItems.size())
+            return fail(KAJO_E_INVALID, "item arrays too small");
+        for (size_t i = 0; i < st.shadowItems.size(); i++) {
+            if (key)
+                key[i] = st.shadowItems[i].key;
+            if (index)
+                index[i] = st.shadowItems[i].index;
+        }
+    }
+    if (st.shadowItems.size() > 0x7fffffffu)
+        return fail(KAJO_E_INVALID, "too many items");
+    return (int)st.shadowItems.size();
+}
+
 int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoParams* params, kajo_hip_t* out)
 {
     if (!scene || !params || !out)
@@ -317,7 +350,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     h->ownStream = true;
 
     // ---- scene -----------------------------------------------------------------------------
-    kajo::stageScene(*scene, h->staged, (p.flags & KAJO_FLAG_NO_GRID) ? 0 : 48);
+    kajo::stageScene(*scene, h->staged, (p.flags & KAJO_FLAG_NO_GRID) ? 0 : 48, !(p.flags & KAJO_FLAG_NO_SHADOW_LISTS));
     const kajo::StagedScene& st = h->staged;
     DSceneView& v = h->view;
     CREATE_TRY(upload(st.planeRow, &v.planeRow, h->sceneBuffers));
@@ -346,6 +379,16 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
             v.grid.cell[k] = st.gridEnabled ? st.gridCell[k] : 1.f;
             v.grid.invCell[k] = st.gridEnabled ? 1.f / st.gridCell[k] : 1.f;
         }
+    }
+    {
+        const uint32_t* start = nullptr;
+        const DShadowItem* items = nullptr;
+        CREATE_TRY(upload(st.shadowStart, &start, h->sceneBuffers));
+        CREATE_TRY(upload(st.shadowItems, &items, h->sceneBuffers));
+        v.shadow.enabled = st.shadowEnabled ? 1 : 0;
+        v.shadow.n = st.shadowN;
+        v.shadow.start = start;
+        v.shadow.items = items;
     }
     v.nPlanes = st.nPlanes;
     v.nSpheres = st.nSpheres;
@@ -947,6 +990,7 @@ int kajo_hip_counters(kajo_hip_t h, KajoCounters* out)
         out->traversals = c[0];
         out->vertices = c[1];
         out->laneSlots = c[2];
+        out->shadowQueries = c[3];
         out->primitiveTests = c[0] * (unsigned long long)(h->view.nPlanes + h->view.nSpheres);
     }
     return KAJO_OK;

@@ -88,6 +88,29 @@ struct DGrid
     int32_t inLds;             // the two arrays are staged into LDS behind the hot records
 };
 
+// Per-light visibility lists (large scenes whose spheres are all world-space balls; stage.cpp buildShadowLists). A shadow ray
+// asks one thing -- is the closest hit the light it was aimed at (Raytracer::canReach, Raytracer.cpp:140-144) -- and every point
+// of it up to the light's surface lies in the convex hull of its origin O and the light's ball (C, r): within r of the segment
+// [C, O]. So only spheres within (their radius + r) of that segment can be hit before the light. For every light the directions
+// u = (O - C) / |O - C| as seen FROM the light are binned on a cube map (6 faces x n x n), and a bin lists the spheres that come
+// that close to some ray C + s u of the bin, sorted by the distance of their near side from C. The query runs the SAME
+// per-sphere arithmetic as the closest-hit walk on the light, the planes and the bin's spheres nearer than O, and applies the
+// walk's acceptance rule in its order-independent form (closest wins; among equal distances the later object): the answer is
+// the brute-force walk's, from a handful of tests instead of a grid walk.
+struct DShadowItem
+{
+    float key;      // |c_i - C| - (radius_i + margin): no point of the ray nearer to C than this can touch sphere i
+    uint32_t index; // sphere index
+};
+
+struct DShadowLists
+{
+    int32_t enabled;
+    int32_t n;                 // bins per cube-face axis
+    const uint32_t* start;     // [nLights * 6 * n * n + 1]
+    const DShadowItem* items;  // ascending key within a bin
+};
+
 struct DSceneView // device pointers + counts, passed to the kernels by value
 {
     const DFloat4* planeRow;    // [nPlanes]
@@ -103,6 +126,7 @@ struct DSceneView // device pointers + counts, passed to the kernels by value
     int32_t planesRigid;        // every plane has |determinant - 1| <= 2^-20 (FAST numerics only)
     float background[3];
     DGrid grid;
+    DShadowLists shadow;
     // camera (Renderer.cpp:29-34): p1, p2 - p1, p3 - p1, origin
     float p1[3], dp2[3], dp3[3], origin[3];
 };

@@ -476,6 +476,102 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     return Hit{best, tMax, bestT0};
 }
 
+// ---- shadow query through the light's visibility lists (large scenes) ------------------------------
+// Raytracer::canReach (Raytracer.cpp:140-144): is the closest hit of the ray the light `si` (sphere index) it was aimed at?
+// Answered from the light itself, the planes and the few spheres that come within reach of the segment light centre ..
+// ray origin (device_scene.h DShadowLists) instead of a closest-hit walk of the grid. Every test is the closest-hit walk's own
+// arithmetic; the walk's acceptance (Raytracer.cpp:115: reject only t > max, objects in scene order, so the closest wins and
+// among equal distances the later object) is applied in its order-independent form: something beats the light iff its
+// distance is smaller, or equal with a later index. Planes precede every sphere, so a plane must be strictly closer.
+KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, int si, F3 O, F3 d)
+{
+    const int np = sc.nPlanes;
+    const float aT = dot(d, d);
+#if KAJO_STRICT
+    float tsL, thL;
+    if (!sphereCandidate(sc, lds, si, O, d, aT, 0.0f, tsL, thL) || tsL < 0.0f)
+        return false;
+    bool blocked = false;
+    for (int i = 0; i < np; i++) { // Raytracer.cpp:74-98, as in trace()
+        const DFloat4 r = lds.planeRow[i];
+        const float det = lds.planeDet[i];
+        float denom = r.x * d.x + r.y * d.y + r.z * d.z;
+        float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w * 1.0f;
+        float t = kdiv(-oy, denom);
+        float ts = t * det;
+        blocked = blocked || (!(__builtin_fabsf(denom) < kFltEpsilon) && !(t < 0.0f) && !(ts < 0.0f) && ts < tsL);
+    }
+    if (blocked)
+        return false;
+#else
+    const float iaT = krcp(aT);
+    uint32_t kL;
+    {
+        const DFloat4 s = lds.sphereHot[si];
+        F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+        float h = dot(d, o);
+        float c = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, __builtin_fmaf(o.z, o.z, -s.w)));
+        float sq = ksqrt(h * h - aT * c);
+        const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
+        kL = klo < khi ? klo : khi; // the smaller non-negative root; a negative root or NaN sorts above +inf (trace())
+    }
+    if (kL > 0x7f800000u)
+        return false;
+    bool blocked = false;
+    for (int i = 0; i < np; i++) {
+        const DFloat4 r = lds.planeRow[i];
+        float denom = r.x * d.x + r.y * d.y + r.z * d.z;
+        float oy = __builtin_fmaf(r.x, O.x, __builtin_fmaf(r.y, O.y, __builtin_fmaf(r.z, O.z, r.w)));
+        // (the lists are built with the grid, which needs every plane rigid: trace()'s rigid-plane form)
+        const uint32_t kt = __builtin_bit_cast(uint32_t, __builtin_fmaf(-oy, krcp(denom), 0.0f));
+        blocked = blocked || (!(__builtin_fabsf(denom) < kFltEpsilon) && kt < kL);
+    }
+    if (blocked)
+        return false;
+#endif
+    // the bin of u = O - C on the light's cube map, and how far from C the ray reaches
+    const DSphereCold& lc = lds.lightCold[lightK];
+    const F3 u = f3(O.x - lc.cx, O.y - lc.cy, O.z - lc.cz);
+    const float ax = __builtin_fabsf(u.x), ay = __builtin_fabsf(u.y), az = __builtin_fabsf(u.z);
+    const int m = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
+    const float um = m == 0 ? u.x : (m == 1 ? u.y : u.z);
+    const float ua = m == 0 ? u.y : (m == 1 ? u.z : u.x);
+    const float ub = m == 0 ? u.z : (m == 1 ? u.x : u.y);
+    const float im = 1.0f / __builtin_fabsf(um); // (u == 0: NaN coordinates fall into cell 0 -- a sphere that close to C is in every bin)
+    const int N = sc.shadow.n;
+    const float halfN = 0.5f * (float)N;
+    int ia = (int)__builtin_floorf((ua * im + 1.0f) * halfN), ib = (int)__builtin_floorf((ub * im + 1.0f) * halfN);
+    ia = min(max(ia, 0), N - 1);
+    ib = min(max(ib, 0), N - 1);
+    const int face = 2 * m + (um < 0.0f ? 1 : 0);
+    const uint32_t bin = (uint32_t)((((lightK * 6 + face) * N) + ib) * N + ia);
+    const uint32_t k0 = sc.shadow.start[bin], e = sc.shadow.start[bin + 1];
+    const float reach = fmaxf(ksqrt(dot(u, u)), lc.radius) * 1.000001f;
+    for (uint32_t k = k0; k < e; k++) {
+        const DShadowItem it = sc.shadow.items[k];
+        if (it.key > reach) // sorted: nothing further along the list can touch the ray before it ends
+            break;
+        const int i = (int)it.index;
+#if KAJO_STRICT
+        float ts, th;
+        const bool valid = sphereCandidate(sc, lds, i, O, d, aT, 0.0f, ts, th);
+        if (valid && !(ts < 0.0f) && (ts < tsL || (ts == tsL && i > si)))
+            return false;
+#else
+        const DFloat4 s = lds.sphereHot[i];
+        F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+        float h = dot(d, o);
+        float c = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, __builtin_fmaf(o.z, o.z, -s.w)));
+        float sq = ksqrt(h * h - aT * c);
+        const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
+        const uint32_t kth = klo < khi ? klo : khi;
+        if (kth < kL || (kth == kL && i > si))
+            return false;
+#endif
+    }
+    return true;
+}
+
 // ---- surface point of an accepted hit ------------------------------------------------------
 struct Surface
 {
@@ -869,7 +965,11 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
 // them, so that a frame with fewer blocks than the chip has wave slots still fills it. Every pass's term radiance / S
 // goes to an LDS table [pass][pixel]; after a barrier wave 0 adds the terms to the accumulation in pass order -- the
 // float sums are those of one wave doing all the passes.
-template <bool COLD_LDS, bool KAT, bool SPLIT = false>
+// LISTS (large scenes whose spheres are all world-space balls): a light sample's shadow query is answered on the spot from the
+// light's visibility lists (lightReached) instead of costing the lane a trip of its own through the grid: the light loop of a
+// vertex runs to its end in ONE trip, as Shader::sampleLights does (Shader.cpp:50-86), and every trip's walk carries camera and
+// extension rays only. Same draws, same tests, same sums in the same order: the buffer does not change by a bit.
+template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool LISTS = false>
 KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 {
     const DSceneView& sc = args.scene;
@@ -977,7 +1077,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #endif
     float pendP = 0.0f;
 
-    unsigned long long ctrTraversals = 0, ctrVertices = 0, ctrSlots = 0;
+    unsigned long long ctrTraversals = 0, ctrVertices = 0, ctrSlots = 0, ctrShadow = 0;
     const bool counting = args.counters != nullptr;
 #ifdef KAJO_PROFILE
     // block profile: prof[2k] = wave executions of block k, prof[2k+1] = lanes active in it
@@ -1235,7 +1335,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     }
                 }
             }
-        } else if (mode == MODE_SHADOW) {
+        } else if (!LISTS && mode == MODE_SHADOW) {
             // Shader.cpp:72-73: the sample counts iff the closest hit of the shadow ray IS the light
             if (hit.id == np + 1 + lds.light[lightK]) {
 #if KAJO_STRICT
@@ -1319,6 +1419,19 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 const DFloat4 le = lds.lightEmission[lightK];
                 const F3 Le = f3(le.x, le.y, le.z);
                 pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
+                if (LISTS) { // Shader.cpp:66-73 on the spot
+                    if (counting)
+                        ctrShadow += 1;
+                    if (lightReached(sc, lds, lightK, si, O, l)) {
+#if KAJO_STRICT
+                        vLd = vLd + pendContrib;
+#else
+                        vE = vE + pendContrib;
+#endif
+                    }
+                    lightK++;
+                    continue;
+                }
                 mode = MODE_SHADOW;
                 shadowRay = true;
                 break;
@@ -1425,12 +1538,17 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #endif
     }
     if (counting) {
-        // vertices are per lane: reduce over the wave first
-        unsigned long long v = ctrVertices;
-        for (int o = 32; o > 0; o >>= 1)
+        // vertices and shadow queries are per lane: reduce over the wave first
+        unsigned long long v = ctrVertices, q = ctrShadow;
+        for (int o = 32; o > 0; o >>= 1) {
             v += __shfl_down(v, o);
-        if (lane == 0)
+            q += __shfl_down(q, o);
+        }
+        if (lane == 0) {
             atomicAdd(&args.counters[1], v);
+            if (LISTS)
+                atomicAdd(&args.counters[3], q);
+        }
     }
 }
 
@@ -1455,6 +1573,13 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBody<false, false>(args, ldsRaw);
+}
+
+// large scenes with per-light visibility lists: shadow queries answered inside the light loop (renderBody LISTS)
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KERNEL_NAME_BIGLIST(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<false, false, false, true>(args, ldsRaw);
 }
 
 // known-answer kernels (kajo_hip_kat_shade / kajo_hip_kat_trace): the SAME device functions, fed rays

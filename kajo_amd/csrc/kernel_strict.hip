@@ -2,6 +2,7 @@
 #define KAJO_STRICT 1
 #define KAJO_KERNEL_NAME kajo_render_strict
 #define KAJO_KERNEL_NAME_BIG kajo_render_strict_big
+#define KAJO_KERNEL_NAME_BIGLIST kajo_render_strict_biglist
 #define KAJO_KERNEL_NAME_SPLIT kajo_render_strict_split
 #define KAJO_KAT_SHADE_NAME kajo_kat_shade_strict
 #define KAJO_KAT_TRACE_NAME kajo_kat_trace_strict

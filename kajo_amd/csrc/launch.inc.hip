@@ -2,12 +2,15 @@
 #define KAJO_CAT2(a, b) a##b
 #define KAJO_CAT(a, b) KAJO_CAT2(a, b)
 
-// coldInLds: 1 = whole scene staged in LDS (KAJO_KERNEL_NAME), 0 = cold records stay global
+// coldInLds: 1 = whole scene staged in LDS (KAJO_KERNEL_NAME), 0 = cold records stay global (the scene's shadow.enabled picks
+// the kernel that answers shadow queries from the lights' visibility lists)
 extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _launch)(const RenderArgs* args, int coldInLds, unsigned grid, unsigned block,
                                                 size_t ldsBytes, void* stream)
 {
     if (coldInLds)
         hipLaunchKernelGGL(KAJO_KERNEL_NAME, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
+    else if (args->scene.shadow.enabled)
+        hipLaunchKernelGGL(KAJO_KERNEL_NAME_BIGLIST, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
     else
         hipLaunchKernelGGL(KAJO_KERNEL_NAME_BIG, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
     return (int)hipGetLastError();
@@ -29,8 +32,14 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(int coldInLds, size_t ldsByt
     const int k = coldInLds ? 1 : 0;
     if (ldsBytes <= highWater[k])
         return (int)hipSuccess;
-    const void* fn = coldInLds ? reinterpret_cast<const void*>(KAJO_KERNEL_NAME) : reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIG);
-    const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    hipError_t e;
+    if (coldInLds) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    } else {
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIG), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIGLIST), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+    }
     if (e == hipSuccess)
         highWater[k] = ldsBytes;
     return (int)e;

@@ -12,6 +12,7 @@
 #include "stage.h"
 #include "tuning.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -288,9 +289,153 @@ void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
     out.gridEnabled = true;
 }
 
+// Per-light visibility lists (device_scene.h DShadowLists). Conservative by construction: a sphere is left out of a bin only
+// if NO ray from the light's centre C through the bin comes within R_i = sqrt(radius_i^2 + E) + r_light + pad of its centre,
+// where E covers what binary32 rounding can add to the discriminant b^2 - 4ac of Raytracer.cpp:26-30 at this scene's
+// distances (a sphere the exact line misses by less than sqrt(radius^2 + E) - radius may still be "hit" in float arithmetic,
+// and the brute-force walk would see that hit), and pad the rounding of the binning itself.
+void buildShadowLists(const KajoScene& s, StagedScene& out, bool wanted)
+{
+    out.shadowEnabled = false;
+    const int n = s.nSpheres, nL = (int)out.light.size();
+    if (!wanted || !out.gridEnabled || !out.allTranslated || nL == 0)
+        return;
+    int N = 32; // bins per cube-face axis: 6144 direction bins per light (1000 spheres / 16 lights: 7.8 candidate spheres per query
+                // and 2.2 MB of lists; 16: 15.1 and 0.9 MB; 64: 5.1 and 6.8 MB -- the tube of radius r_light alone holds ~4)
+    KAJO_TUNE_INT("KAJO_SHADOW_BINS", 2, 64, N);
+    const size_t binsPerLight = (size_t)6 * N * N;
+    if ((size_t)nL * binsPerLight > ((size_t)1 << 22))
+        return;
+    // scene extent: sphere bounds and the camera
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int i = 0; i < n; i++)
+        for (int k = 0; k < 3; k++) {
+            const double c = load(s.spheres[i].transform).e(3, k), r = s.spheres[i].radius;
+            lo[k] = std::fmin(lo[k], c - r);
+            hi[k] = std::fmax(hi[k], c + r);
+        }
+    {
+        const Mat4 view = load(s.camera.transform);
+        const float zero[4] = {0.f, 0.f, 0.f, 1.f};
+        float o[4];
+        transform(inverse(view), zero, o);
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::fmin(lo[k], (double)o[k]);
+            hi[k] = std::fmax(hi[k], (double)o[k]);
+        }
+    }
+    double diag2 = 0;
+    for (int k = 0; k < 3; k++)
+        diag2 += (hi[k] - lo[k]) * (hi[k] - lo[k]);
+    const double E = 4e-7 * 4.0 * diag2; // rounding of b^2 - 4ac / 4a at twice the scene's diagonal, with a factor of two in hand
+    // bins: centre direction and bounding half-angle (as cosine / sine pairs are not needed: angles are compared directly)
+    struct Bin
+    {
+        double q[3], beta;
+    };
+    std::vector<Bin> bins(binsPerLight);
+    auto dirOf = [&](int f, double ua, double ub, double d[3]) {
+        const int m = f >> 1, a = (m + 1) % 3, b = (m + 2) % 3;
+        d[m] = (f & 1) ? -1.0 : 1.0;
+        d[a] = ua;
+        d[b] = ub;
+        const double l = std::sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+        d[0] /= l, d[1] /= l, d[2] /= l;
+    };
+    auto angle = [](const double x[3], const double y[3]) {
+        const double c = x[0] * y[0] + x[1] * y[1] + x[2] * y[2];
+        return std::acos(c > 1 ? 1 : (c < -1 ? -1 : c));
+    };
+    for (int f = 0; f < 6; f++)
+        for (int ib = 0; ib < N; ib++)
+            for (int ia = 0; ia < N; ia++) {
+                Bin& B = bins[((size_t)f * N + ib) * N + ia];
+                dirOf(f, (ia + .5) * 2.0 / N - 1, (ib + .5) * 2.0 / N - 1, B.q);
+                B.beta = 0;
+                for (int c = 0; c < 4; c++) {
+                    double d[3];
+                    dirOf(f, (ia + (c & 1)) * 2.0 / N - 1, (ib + (c >> 1)) * 2.0 / N - 1, d);
+                    B.beta = std::fmax(B.beta, angle(B.q, d));
+                }
+            }
+    // blocks of 8 x 8 bins with a bounding cone of their own: a sphere's cone of directions is tested against the block first
+    const int BS = 8, NB = (N + BS - 1) / BS;
+    std::vector<Bin> blocks((size_t)6 * NB * NB);
+    for (int f = 0; f < 6; f++)
+        for (int jb = 0; jb < NB; jb++)
+            for (int ja = 0; ja < NB; ja++) {
+                Bin& B = blocks[((size_t)f * NB + jb) * NB + ja];
+                const int a0 = ja * BS, a1 = std::min(N, a0 + BS), b0 = jb * BS, b1 = std::min(N, b0 + BS);
+                dirOf(f, (a0 + a1) * 1.0 / N - 1, (b0 + b1) * 1.0 / N - 1, B.q);
+                B.beta = 0;
+                for (int c = 0; c < 4; c++) {
+                    double d[3];
+                    dirOf(f, ((c & 1) ? a1 : a0) * 2.0 / N - 1, ((c >> 1) ? b1 : b0) * 2.0 / N - 1, d);
+                    B.beta = std::fmax(B.beta, angle(B.q, d));
+                }
+            }
+    const double kPiHalf = 1.5707963267948966, faceCone = 0.9553166181245093 /* acos(1 / sqrt 3) */, angPad = 1e-4;
+    std::vector<std::vector<DShadowItem>> lists((size_t)nL * binsPerLight);
+    for (int L = 0; L < nL; L++) {
+        const int sl = out.light[L];
+        const Mat4 ML = load(s.spheres[sl].transform);
+        const double C[3] = {ML.e(3, 0), ML.e(3, 1), ML.e(3, 2)}, rL = s.spheres[sl].radius;
+        for (int i = 0; i < n; i++) {
+            if (i == sl)
+                continue; // the light itself is always tested, first
+            const Mat4 M = load(s.spheres[i].transform);
+            const double w[3] = {M.e(3, 0) - C[0], M.e(3, 1) - C[1], M.e(3, 2) - C[2]}, rho = s.spheres[i].radius;
+            const double D = std::sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+            const double mag = std::fabs(C[0]) + std::fabs(C[1]) + std::fabs(C[2]) + std::fabs(w[0]) + std::fabs(w[1]) + std::fabs(w[2]);
+            const double R = std::sqrt(rho * rho + E) + rL + 2e-3 + 1e-5 * mag;
+            const DShadowItem item{(float)((D - R) * (1 - 1e-6) - 1e-6), (uint32_t)i}; // (rounded down: a key never exceeds the true bound)
+            const bool everywhere = D <= R;
+            const double alpha = everywhere ? 4.0 : std::asin(R / D) + angPad;
+            const double wd[3] = {everywhere ? 1.0 : w[0] / D, everywhere ? 0.0 : w[1] / D, everywhere ? 0.0 : w[2] / D};
+            for (int f = 0; f < 6; f++) {
+                if (!everywhere) {
+                    double axis[3] = {0, 0, 0};
+                    axis[f >> 1] = (f & 1) ? -1.0 : 1.0;
+                    if (angle(wd, axis) > alpha + faceCone + angPad && alpha < kPiHalf)
+                        continue; // the cone of directions toward the sphere misses this face
+                }
+                for (int jb = 0; jb < NB; jb++)
+                    for (int ja = 0; ja < NB; ja++) {
+                        const Bin& K = blocks[((size_t)f * NB + jb) * NB + ja];
+                        if (!everywhere && angle(wd, K.q) > alpha + K.beta + angPad)
+                            continue;
+                        for (int ib = jb * BS; ib < std::min(N, jb * BS + BS); ib++)
+                            for (int ia = ja * BS; ia < std::min(N, ja * BS + BS); ia++) {
+                                const size_t b = ((size_t)f * N + ib) * N + ia;
+                                if (everywhere || angle(wd, bins[b].q) <= alpha + bins[b].beta)
+                                    lists[(size_t)L * binsPerLight + b].push_back(item);
+                            }
+                    }
+            }
+        }
+    }
+    size_t total = 0;
+    for (auto& l : lists)
+        total += l.size();
+    if (total > ((size_t)1 << 25))
+        return;
+    out.shadowStart.assign(lists.size() + 1, 0);
+    out.shadowItems.clear();
+    out.shadowItems.reserve(total);
+    for (size_t b = 0; b < lists.size(); b++) {
+        auto& l = lists[b];
+        std::stable_sort(l.begin(), l.end(), [](const DShadowItem& x, const DShadowItem& y) { return x.key < y.key; });
+        out.shadowStart[b] = (uint32_t)out.shadowItems.size();
+        out.shadowItems.insert(out.shadowItems.end(), l.begin(), l.end());
+    }
+    out.shadowStart[lists.size()] = (uint32_t)out.shadowItems.size();
+    out.shadowN = N;
+    out.shadowEnabled = true;
+}
+
 } // namespace
 
-void stageScene(const KajoScene& s, StagedScene& out, int gridMinSpheres)
+void stageScene(const KajoScene& s, StagedScene& out, int gridMinSpheres, bool shadowLists)
 {
     out = StagedScene();
     out.nPlanes = s.nPlanes;
@@ -368,6 +513,7 @@ void stageScene(const KajoScene& s, StagedScene& out, int gridMinSpheres)
     }
 
     buildGrid(s, out, gridMinSpheres);
+    buildShadowLists(s, out, shadowLists);
 
     // camera basis, Renderer.cpp:29-34
     const Mat4 view = load(s.camera.transform);

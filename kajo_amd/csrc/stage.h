@@ -30,9 +30,15 @@ struct StagedScene
     float gridMin[3], gridMax[3], gridCell[3];
     std::vector<uint32_t> gridCellStart;
     std::vector<uint16_t> gridItems;
+    // per-light visibility lists for shadow queries (device_scene.h DShadowLists; built with the grid when every sphere is a
+    // world-space ball)
+    bool shadowEnabled = false;
+    int shadowN = 0;
+    std::vector<uint32_t> shadowStart;
+    std::vector<DShadowItem> shadowItems;
 };
 
-void stageScene(const KajoScene& scene, StagedScene& out, int gridMinSpheres = 48);
+void stageScene(const KajoScene& scene, StagedScene& out, int gridMinSpheres = 48, bool shadowLists = true);
 
 } // namespace kajo
 

@@ -140,3 +140,25 @@ def stage_scene(scene: Scene):
     pod = scene.pod()
     capi.check(L.kajo_hip_stage_scene(C.byref(pod), inv.ctypes.data_as(C.c_void_p), basis.ctypes.data_as(C.c_void_p)))
     return inv, basis
+
+
+def stage_shadow_lists(scene: Scene):
+    """Host-only: the per-light visibility lists create() stages for a large scene (device_scene.h DShadowLists), or None when
+    the scene gets none. -> dict(n=bins per cube-face axis, lights=[sphere index], start=[nLights * 6 n^2 + 1], key, index)."""
+    L = capi.lib()
+    pod = scene.pod()
+    n, nl = C.c_int32(), C.c_int32()
+    items = L.kajo_hip_stage_shadow_lists(C.byref(pod), C.byref(n), C.byref(nl), None, None, 0, None, None, 0)
+    if items < 0:
+        capi.check(items)
+    if n.value == 0:
+        return None
+    lights = np.zeros(nl.value, np.int32)
+    start = np.zeros(nl.value * 6 * n.value * n.value + 1, np.uint32)
+    key = np.zeros(items, np.float32)
+    index = np.zeros(items, np.uint32)
+    rc = L.kajo_hip_stage_shadow_lists(C.byref(pod), C.byref(n), C.byref(nl), lights.ctypes.data_as(C.c_void_p), start.ctypes.data_as(C.c_void_p),
+                                       start.size, key.ctypes.data_as(C.c_void_p), index.ctypes.data_as(C.c_void_p), items)
+    if rc < 0:
+        capi.check(rc)
+    return dict(n=n.value, lights=lights, start=start, key=key, index=index)

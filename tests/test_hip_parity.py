@@ -129,6 +129,31 @@ def test_grid_walk_equals_brute_force(O, scenes):
         assert bits_equal(a, brute), sc.name
 
 
+def test_shadow_lists_equal_the_grid_walk(O, scenes):
+    """Large scenes whose spheres are all balls answer a light sample's shadow query inside the light loop from the light's
+    visibility lists (integrator.inc.hip lightReached) instead of giving the shadow ray a trip of its own through the grid
+    (KAJO_FLAG_NO_SHADOW_LISTS: round 3's schedule). Same draws, same per-object arithmetic, same acceptance rule: STRICT is the
+    oracle bit for bit either way, FAST the same buffer either way; the walk counts show where the shadow rays went."""
+    from kajo_amd import capi
+    base = scenes["spheres_a169"]
+    for sc, W, H, S, passes in ((stress_scene(base, 300, 6, seed=7), 96, 54, 9, 2), (stress_scene(base, 1000, 16), 80, 45, 4, 3)):
+        want = O.create(sc, math=1).render(W, H, S=S, passes=passes, seed=SEED, depth_limit=8)
+        got = {}
+        for strict in (True, False):
+            for flags in (0, capi.KAJO_FLAG_NO_SHADOW_LISTS):
+                with HipRenderer(sc, W, H, spp=S, seed=SEED, strict=strict, counters=True, flags=flags, passes_per_launch=2) as r:
+                    got[strict, flags] = (r.render(passes).radiance(), r.counters())
+        for flags in (0, capi.KAJO_FLAG_NO_SHADOW_LISTS):
+            g = got[True, flags][0][..., :3]
+            assert ((g.view(np.uint32) == want[..., :3].view(np.uint32)) | (np.isnan(g) & np.isnan(want[..., :3]))).all(), (sc.name, flags)
+        assert bits_equal(got[False, 0][0], got[False, capi.KAJO_FLAG_NO_SHADOW_LISTS][0]), sc.name
+        for strict in (True, False):
+            a, b = got[strict, 0][1], got[strict, capi.KAJO_FLAG_NO_SHADOW_LISTS][1]
+            assert b["shadowQueries"] == 0 and a["shadowQueries"] > 0
+            assert a["traversals"] + a["shadowQueries"] == b["traversals"], (sc.name, strict, a, b)  # every shadow ray is one or the other
+            assert a["vertices"] == b["vertices"]
+
+
 def test_strict_passes_split_and_reset(scenes):
     sc = scenes["spheres_a1"]
     with HipRenderer(sc, 40, 24, strict=True, passes_per_launch=1) as a, HipRenderer(sc, 40, 24, strict=True) as b:

@@ -60,3 +60,33 @@ def feature_crops(scene, W, H, max_spheres=6):
             rects.add(c[1:])
             out.append(c)
     return out
+
+
+def mirror_crop(scene, W, H):
+    """A crop where camera rays land on a plane with an ideal-mirror material (specular colour, exponent 0). Located with the
+    oracle's closest-hit walk on a coarse grid of camera rays (test infrastructure)."""
+    from oraclelib import OracleLib
+    pl = scene.planes
+    mirrors = [i + 1 for i in range(scene.n_planes) if pl[i, 16 + 8:16 + 11].sum() > 0 and pl[i, 16 + 20] == 0 and pl[i, 16 + 4:16 + 7].sum() == 0]
+    if not mirrors:
+        return None
+    h = OracleLib("oracle").create(scene, 0)
+    p1, p2, p3, origin = h.camera_basis().astype(np.float64)
+    gx, gy = np.meshgrid((np.arange(48) + .5) / 48, (np.arange(27) + .5) / 27)
+    d = p1 + gx.reshape(-1, 1) * (p2 - p1) + (1 - gy.reshape(-1, 1)) * (p3 - p1) - origin
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    idx = h.trace(np.repeat(origin[None], len(d), 0), d)["idx"].reshape(27, 48)
+    ys, xs = np.nonzero(np.isin(idx, mirrors))
+    if len(xs) == 0:
+        return None
+    k = len(xs) // 2
+    return ("mirror wall", *_clamp((xs[k] + .5) / 48 * W, (ys[k] + .5) / 27 * H, W, H))
+
+
+def crops_for(scene, W, H, limit=10):
+    """The crops the workload tests compare: feature crops with the mirror-wall crop in fourth place."""
+    crops = feature_crops(scene, W, H)
+    m = mirror_crop(scene, W, H)
+    if m:
+        crops.insert(3, m)
+    return crops[:limit]

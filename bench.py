@@ -208,6 +208,34 @@ def other_mode_leg(scene, W, H, passes, ppl, local_rank, strict, fpp):
             "parity": parity_leg(scene, mk, strict, passes)}
 
 
+def scheduler_run_leg(scene, W, H, passes, frames=8):
+    """The path a Kajo user runs: hip::Scheduler::run() behind the reference's plugin interface (renderer/Scheduler.h:12-16),
+    driven by the headless kajo_render binary in a CHILD process (its own HIP context; started before this process touches the
+    GPU). Every refresh renders `passes` passes, composes, resolves and copies the ARGB8 image into Image::pixels on the host
+    (renderer/cpu/Renderer.cpp:73-75 writes Image::pixels in place), synchronously. Reported from the refreshes after the
+    first (which loads the kernels and records the launch order)."""
+    import tempfile
+    exe = os.path.join(ROOT, "kajo_amd", "host", "kajo_render")
+    if not os.path.exists(exe):
+        return None
+    with tempfile.TemporaryDirectory() as tmp:
+        pod = os.path.join(tmp, "scene.pod")
+        scene.write_pod(pod)
+        cmd = [exe, "-w", str(W), "-h", str(H), "-r", "hip", "--passes", str(passes * (frames + 2)), "--batch", str(passes), "--gpus", "1",
+               "-o", "", "--json", "--scene-pod", pod]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    if p.returncode != 0:
+        return {"error": (p.stderr or p.stdout)[-400:]}
+    st = json.loads(p.stdout.strip().splitlines()[-1])
+    ms = sorted(st["batch_ms"][2:])
+    med = ms[len(ms) // 2]
+    n = int(math.sqrt(SPP))
+    return {"value": W * H * n * n * passes / (med * 1e-3) / 1e6, "unit": "Msamples/s", "ms_per_frame": med,
+            "first_frame_ms": st["batch_ms"][0], "frames_timed": len(ms), "passes_per_frame": passes,
+            "includes": "render kernel + compose + resolve + host ARGB8 read-back of %d bytes into Image::pixels, one synchronous refresh per frame" % (W * H * 4),
+            "command": "kajo_render -w %d -h %d -r hip --passes %d --batch %d --gpus 1 --json --scene-pod <spheres.json fixture>" % (W, H, passes * (frames + 2), passes)}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -228,6 +256,9 @@ def main():
     ap.add_argument("--fast", action="store_true", help="time the FAST kernels")
     ap.add_argument("--passes-per-launch", type=int, default=0)
     ap.add_argument("--no-check", action="store_true", help="N > 1: skip the bit-for-bit check against a one-GPU frame")
+    ap.add_argument("--separate-compose", action="store_true",
+                    help="N > 1: rank 0 composes the whole float frame and resolves that (two passes over the data, rounds 1-3) instead "
+                         "of resolving straight from the gathered tile buffers")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo: rehearsal of the N > 1 control flow on fewer GPUs than ranks (gather staged through "
                          "host memory, every rank on GPU LOCAL_RANK %% device_count); the graded runs use nccl = RCCL")
@@ -245,6 +276,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    sched_leg = None
+    if world == 1 and not args.no_cpu_baseline and args.workload in ("auto", "c2") and torch.cuda.device_count() > 0:
+        # the plugin path, in a child process, BEFORE this process initialises the GPU (device_count() does not)
+        from kajo_amd.scene import Scene as _Scene
+        _z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+        sched_leg = scheduler_run_leg(_Scene.from_npz(_z, "spheres_a169/", "spheres.json 16:9"), *WORKLOADS["c2"][:3])
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the backend has no CPU path")
     if args.backend == "gloo":
@@ -309,10 +346,13 @@ def main():
                 if rank == 0:
                     gathered.copy_(host)
             ev[1].record()
-            if rank == 0:
+            if rank == 0 and args.separate_compose:
                 r.compose(gathered.data_ptr())
         if rank == 0:
-            capi.check(L.kajo_hip_resolve_argb8_device(r._h, C.c_void_p(argb.data_ptr())))
+            if world > 1 and not args.separate_compose:  # compose + resolve in one pass over the gathered tile buffers
+                capi.check(L.kajo_hip_resolve_gathered_argb8_device(r._h, C.c_void_p(gathered.data_ptr()), C.c_void_p(argb.data_ptr())))
+            else:
+                capi.check(L.kajo_hip_resolve_argb8_device(r._h, C.c_void_p(argb.data_ptr())))
         ev[2].record()
         stream.synchronize()
         if timed and world > 1:
@@ -359,6 +399,7 @@ def main():
             step()
         fence()
         if rank == 0:
+            r.compose(gathered.data_ptr())  # (the float frame is only composed when somebody reads it)
             got = r.radiance()
             solo = factory(W, H)
             solo.render(PASSES).wait()  # warm: the first launch also records the launch order
@@ -368,10 +409,12 @@ def main():
             solo_dt = time.perf_counter() - ts
             s1 = solo.counters()
             want = solo.radiance()
+            want_px = solo.argb8()
             solo.close()
             same = np.array_equal(got.view(np.uint32), want.view(np.uint32))
+            same_px = np.array_equal(argb.cpu().numpy().view(np.uint32).reshape(H, W), want_px)
             solo_value = (s1["paths"] - s0["paths"]) / solo_dt / 1e6
-            check = {"frame_bit_identical_to_one_gpu": bool(same), "steps_compared": 2,
+            check = {"frame_bit_identical_to_one_gpu": bool(same), "argb8_bit_identical_to_one_gpu": bool(same_px), "steps_compared": 2,
                      "one_gpu_same_frame_value": solo_value, "one_gpu_same_frame_ms": solo_dt * 1e3,
                      "speedup_vs_one_gpu_same_frame": value / solo_value,
                      "efficiency_vs_one_gpu_same_frame": value / solo_value / world}
@@ -437,6 +480,8 @@ def main():
             out["multi_gpu"] = {"kernel_ms_per_step_by_rank": km, "kernel_ms_imbalance": max(km) / max(min(km), 1e-9),
                                 "gather_ms_by_rank": [p[1] for p in per_rank],
                                 "compose_resolve_ms_rank0": float(np.mean(tail_ms or [0.0])),
+                                "compose_resolve": "separate kernels (whole float frame written and read back)" if args.separate_compose
+                                                   else "one kernel, straight from the gathered tile buffers",
                                 "paths_per_step_by_rank": [p[2] for p in per_rank],
                                 "gather_bytes_per_peer": nbytes}
             if check:
@@ -444,6 +489,10 @@ def main():
     r.close()
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # the parity legs first, the timed CPU baseline last (its libraries are built with the reference's fast-math flags)
+        if sched_leg:
+            # hip::Scheduler::run() on the same frame (FAST kernels), next to ms_per_step: the difference is the 8 MB host read-back
+            # and the synchronous refresh
+            out["scheduler_run"] = sched_leg
         out["parity"] = parity_leg(scene, factory, strict, PASSES)
         other = other_mode_leg(scene, W, H, PASSES, ppl, local_rank, not strict, out["roofline"]["flops_per_path"])
         out["cpu_baseline"] = cpu_baseline(scene, W, H)

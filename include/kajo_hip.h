@@ -132,6 +132,12 @@ int kajo_hip_tile_buffer(kajo_hip_t h, void** devicePtr, size_t* bytes);
    tileCount == 1 composition happens implicitly. */
 int kajo_hip_compose(kajo_hip_t h, const void* gathered);
 
+/* The ARGB8 image straight from gathered tile buffers (DEVICE pointer, tileCount consecutive buffers in rank order; NULL = this
+   handle's own buffer when tileCount == 1), into DEVICE memory, asynchronous on the handle's stream: compose + resolve in
+   one pass over the data, without the whole-frame float buffer (renderer/cpu/Renderer.cpp:70-75 per pixel, as
+   kajo_hip_resolve_argb8_device). kajo_hip_compose stays for kajo_hip_read_radiance. */
+int kajo_hip_resolve_gathered_argb8_device(kajo_hip_t h, const void* gathered, void* dst);
+
 /* Use an existing HIP stream (hipStream_t passed as void*) instead of the handle's own. */
 int kajo_hip_set_stream(kajo_hip_t h, void* stream);
 

@@ -32,6 +32,8 @@ int kajo_render_fast_set_lds(int coldInLds, size_t lds);
 int kajo_render_strict_set_lds(int coldInLds, size_t lds);
 int kajo_resolve_fast_launch(const void* frame, int count, float passes, void* dst, void* stream);
 int kajo_resolve_strict_launch(const void* frame, int count, float passes, void* dst, void* stream);
+int kajo_resolve_tiles_fast_launch(const void* gathered, const TileMap* map, float passes, void* dst, void* stream);
+int kajo_resolve_tiles_strict_launch(const void* gathered, const TileMap* map, float passes, void* dst, void* stream);
 int kajo_compose_launch(const void* gathered, const TileMap* map, void* frame, void* stream);
 int kajo_kat_shade_fast_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_kat_shade_strict_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
@@ -112,7 +114,7 @@ struct KajoHip
     int passesDone = 0;
     size_t ldsBytes = 0, hotBytes = 0;
     int stealWindow = 4; // render_args.h; 1 when a large scene needs the LDS for its grid
-    int thrL = 1;        // integrator.inc.hip MODE_HOLD
+    int thrL = 1, holdTrips = 1; // integrator.inc.hip MODE_HOLD
     int ldsExtra = 0;    // (KAJO_TUNING builds only) unused bytes per wave, to study a launch at a lower occupancy
     size_t perWaveBytes(bool withMailbox) const { return (size_t)ldsExtra + (withMailbox ? (size_t)64 * stealWindow * 16 : 0); }
     void fillWaveLds(RenderArgs& a, size_t perWaveOffset, bool withMailbox) const
@@ -120,6 +122,7 @@ struct KajoHip
         a.perWaveOffset = (uint32_t)perWaveOffset;
         a.perWaveBytes = (uint32_t)perWaveBytes(withMailbox);
         a.thrL = thrL;
+        a.holdTrips = holdTrips;
     }
     int coldInLds = 1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> pending; // kernel timing
@@ -407,7 +410,8 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     // cold records too while the total stays small enough for four workgroups per CU (160 KiB / 4).
     // (integrator.inc.hip stageToLds: the 4-byte arrays are padded to a 16-byte boundary before the light records)
     const size_t hotBytes = (size_t)v.nPlanes * 16 + (size_t)v.nSphereHot * 16 +
-                            ((((size_t)v.nPlanes + (v.allTranslated ? 0 : v.nSpheres) + v.nLights) * 4 + 15) & ~(size_t)15) + (size_t)v.nLights * (64 + 16) + 7 * 16;
+                            ((((size_t)v.nPlanes + (v.allTranslated ? 0 : v.nSpheres) + v.nLights) * 4 + 15) & ~(size_t)15) + (size_t)v.nLights * (64 + 16) +
+                            ((((size_t)v.nLights * v.nPlanes) * 4 + 15) & ~(size_t)15) + 7 * 16;
     const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * sizeof(DMaterial);
     // What every wave adds to the scene copy (render_args.h): the mailbox of taken-over passes.
     // The sizes below are constants of the product library. A -DKAJO_TUNING build (libkajo_hip_tune.so, tools/ only) reads
@@ -420,7 +424,18 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     // integrator.inc.hip MODE_HOLD: lanes that must want the light / BSDF blocks before they run without any lane having
     // waited a trip; 1 = every trip. Large scenes run them every trip (16 lights: most lanes are in them anyway).
     h->thrL = big ? 1 : (h->strict() ? 28 : 20);
+    h->holdTrips = 1;
+    if (st.shadowEnabled) {
+        // Large scenes with visibility lists: the light loop runs to its end inside one trip (16 lights: ~10 rounds of light
+        // sample + shadow query) and is the expensive block of a trip, with a third of the lanes in it. It runs when 48 lanes
+        // have a vertex waiting or it has been put off three trips in a row; the walk loses lanes to the waiting (lane
+        // efficiency 0.975 -> 0.675) and still the launch gains: FAST 2.35 -> 4.34 G paths/s on the 1000-sphere scene at
+        // 4K x 32 passes, STRICT 1.51 -> 2.54 (profiles/r04_c5_sweep.txt).
+        h->thrL = 48;
+        h->holdTrips = 3;
+    }
     KAJO_TUNE_INT("KAJO_THR_L", 1, 65, h->thrL);
+    KAJO_TUNE_INT("KAJO_HOLD_TRIPS", 1, 16, h->holdTrips);
     size_t gridBytes = 0;
     const size_t gridHeaderBytes = st.gridEnabled ? 4 * 16 : 0; // always in LDS (integrator.inc.hip gridWalk)
     if (st.gridEnabled) {
@@ -763,6 +778,27 @@ int kajo_hip_compose(kajo_hip_t h, const void* gathered)
     return KAJO_OK;
 }
 
+int kajo_hip_resolve_gathered_argb8_device(kajo_hip_t h, const void* gathered, void* dst)
+{
+    if (!h || !dst)
+        return fail(KAJO_E_INVALID, "null argument");
+    int rc = bind(h);
+    if (rc)
+        return rc;
+    if (h->passesDone < 1)
+        return fail(KAJO_E_STATE, "nothing rendered yet");
+    if (!gathered) {
+        if (h->map.tileCount != 1)
+            return fail(KAJO_E_STATE, "a handle that owns part of the frame needs the gathered tile buffers");
+        gathered = h->tiles;
+    }
+    hipError_t le = (hipError_t)(h->strict() ? kajo_resolve_tiles_strict_launch(gathered, &h->map, (float)h->passesDone, dst, h->stream)
+                                             : kajo_resolve_tiles_fast_launch(gathered, &h->map, (float)h->passesDone, dst, h->stream));
+    if (le != hipSuccess)
+        return failHip(le, "resolve kernel launch");
+    return KAJO_OK;
+}
+
 int kajo_hip_resolve_argb8_device(kajo_hip_t h, void* dst)
 {
     if (!h || !dst)
@@ -772,6 +808,10 @@ int kajo_hip_resolve_argb8_device(kajo_hip_t h, void* dst)
         return rc;
     if (h->passesDone < 1)
         return fail(KAJO_E_STATE, "nothing rendered yet");
+    // one owner and no composed frame at hand: resolve straight from the tile buffer (the frame is composed when somebody
+    // asks for the float radiance)
+    if (!h->frameValid && h->map.tileCount == 1)
+        return kajo_hip_resolve_gathered_argb8_device(h, nullptr, dst);
     if ((rc = composeOwn(h)))
         return rc;
     const int count = h->W * h->H;

@@ -172,6 +172,7 @@ struct LdsScene
     const int32_t* light;          // [nLights] sphere indices, always in LDS
     const DSphereCold* lightCold;  // [nLights] the lights' own cold records and
     const DFloat4* lightEmission;  // [nLights] emissions, always in LDS: a large scene's light loop reads nothing from global memory
+    const float* lightPlaneSide;   // [nLights][nPlanes] +1 / -1: the light's whole ball lies on that side of the plane (by a margin); 0: it does not
     const DFloat4* camera;         // [7] p1, p2 - p1, p3 - p1, origin (Renderer.cpp:29-34), background, the pixel / sample sizes of
                                    // Renderer.cpp:39-42, stream key words + W + H: read where a camera ray is formed /
                                    // a ray escapes, instead of fifteen scalar registers held through the whole loop (the loop spills SGPRs)
@@ -491,12 +492,18 @@ KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, in
     float tsL, thL;
     if (!sphereCandidate(sc, lds, si, O, d, aT, 0.0f, tsL, thL) || tsL < 0.0f)
         return false;
+    // A plane that has the ray's origin AND the light's whole ball strictly on one side (by margins far above the rounding of
+    // these sums) is crossed, if at all, behind the origin or beyond the ball: its test cannot come out "hit before the light".
+    // The rays of a wave mostly agree on that (a room: everything is inside), so the rest of the test is skipped per wave.
+    const float tolO = 1e-3f + 1e-5f * (__builtin_fabsf(O.x) + __builtin_fabsf(O.y) + __builtin_fabsf(O.z));
     bool blocked = false;
     for (int i = 0; i < np; i++) { // Raytracer.cpp:74-98, as in trace()
         const DFloat4 r = lds.planeRow[i];
+        float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w * 1.0f;
+        if (__builtin_amdgcn_ballot_w64(!(oy * lds.lightPlaneSide[lightK * np + i] > tolO + 1e-5f * __builtin_fabsf(r.w))) == 0ull)
+            continue;
         const float det = lds.planeDet[i];
         float denom = r.x * d.x + r.y * d.y + r.z * d.z;
-        float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w * 1.0f;
         float t = kdiv(-oy, denom);
         float ts = t * det;
         blocked = blocked || (!(__builtin_fabsf(denom) < kFltEpsilon) && !(t < 0.0f) && !(ts < 0.0f) && ts < tsL);
@@ -517,11 +524,14 @@ KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, in
     }
     if (kL > 0x7f800000u)
         return false;
+    const float tolO = 1e-3f + 1e-5f * (__builtin_fabsf(O.x) + __builtin_fabsf(O.y) + __builtin_fabsf(O.z)); // (see the STRICT twin above)
     bool blocked = false;
     for (int i = 0; i < np; i++) {
         const DFloat4 r = lds.planeRow[i];
-        float denom = r.x * d.x + r.y * d.y + r.z * d.z;
         float oy = __builtin_fmaf(r.x, O.x, __builtin_fmaf(r.y, O.y, __builtin_fmaf(r.z, O.z, r.w)));
+        if (__builtin_amdgcn_ballot_w64(!(oy * lds.lightPlaneSide[lightK * np + i] > tolO + 1e-5f * __builtin_fabsf(r.w))) == 0ull)
+            continue;
+        float denom = r.x * d.x + r.y * d.y + r.z * d.z;
         // (the lists are built with the grid, which needs every plane rigid: trace()'s rigid-plane form)
         const uint32_t kt = __builtin_bit_cast(uint32_t, __builtin_fmaf(-oy, krcp(denom), 0.0f));
         blocked = blocked || (!(__builtin_fabsf(denom) < kFltEpsilon) && kt < kL);
@@ -537,7 +547,8 @@ KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, in
     const float um = m == 0 ? u.x : (m == 1 ? u.y : u.z);
     const float ua = m == 0 ? u.y : (m == 1 ? u.z : u.x);
     const float ub = m == 0 ? u.z : (m == 1 ? u.x : u.y);
-    const float im = 1.0f / __builtin_fabsf(um); // (u == 0: NaN coordinates fall into cell 0 -- a sphere that close to C is in every bin)
+    // (the hardware reciprocal in both numerics modes: the bin only selects the candidate set, which is conservative by 1e-4 rad)
+    const float im = __builtin_amdgcn_rcpf(__builtin_fabsf(um)); // (u == 0: NaN coordinates fall into cell 0 -- a sphere that close to C is in every bin)
     const int N = sc.shadow.n;
     const float halfN = 0.5f * (float)N;
     int ia = (int)__builtin_floorf((ua * im + 1.0f) * halfN), ib = (int)__builtin_floorf((ub * im + 1.0f) * halfN);
@@ -547,11 +558,21 @@ KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, in
     const uint32_t bin = (uint32_t)((((lightK * 6 + face) * N) + ib) * N + ia);
     const uint32_t k0 = sc.shadow.start[bin], e = sc.shadow.start[bin + 1];
     const float reach = fmaxf(ksqrt(dot(u, u)), lc.radius) * 1.000001f;
-    for (uint32_t k = k0; k < e; k++) {
-        const DShadowItem it = sc.shadow.items[k];
-        if (it.key > reach) // sorted: nothing further along the list can touch the ray before it ends
+    // The walk of the bin's list: (key, index) pairs as one 8-byte load each, the NEXT pair requested before the current one is
+    // tested (the lists live in global memory: an L2 round trip per item otherwise, ~8 items per query).
+    const uint2* items = reinterpret_cast<const uint2*>(sc.shadow.items);
+    uint32_t k = k0;
+    uint2 nxt = make_uint2(0x7f800000u, 0u);
+    if (k < e)
+        nxt = items[k];
+    while (k < e) {
+        const uint2 cur = nxt;
+        k++;
+        if (k < e)
+            nxt = items[k];
+        if (__builtin_bit_cast(float, cur.x) > reach) // sorted: nothing further along the list can touch the ray before it ends
             break;
-        const int i = (int)it.index;
+        const int i = (int)cur.y;
 #if KAJO_STRICT
         float ts, th;
         const bool valid = sphereCandidate(sc, lds, i, O, d, aT, 0.0f, ts, th);
@@ -875,7 +896,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     const int np = sc.nPlanes, ns = sc.nSpheres;
     // layout: [planeRow np x16][sphereHot nHot x16]{[planeFrame 3np x16][sphereCold ns x64]
     //         [material (np+ns) x96]}[planeDet np x4][sphereHotOffset ns x4][light nL x4] (pad to 16)
-    //         [lightCold nL x64][lightEmission nL x16][camera 7 x16]{[grid header 4 x16][grid cell starts][grid items]}
+    //         [lightCold nL x64][lightEmission nL x16][lightPlaneSide nL*np x4 (pad to 16)][camera 7 x16]{[grid header 4 x16][grid cell starts][grid items]}
     DFloat4* ldsPlaneRow = reinterpret_cast<DFloat4*>(ldsRaw);
     DFloat4* ldsSphereHot = ldsPlaneRow + np;
     DFloat4* cursor = ldsSphereHot + sc.nSphereHot;
@@ -923,7 +944,18 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
         const DMaterial& lm = sc.material[np + sc.light[i]];
         le4[i] = DFloat4{lm.emission[0], lm.emission[1], lm.emission[2], 0.0f};
     }
-    DFloat4* cam4 = le4 + sc.nLights;
+    // per (light, plane): which side of the plane the light's ball is on (lightReached skips planes the ray cannot cross)
+    float* lps = reinterpret_cast<float*>(le4 + sc.nLights);
+    for (int i = threadIdx.x; i < sc.nLights * np; i += blockDim.x) {
+        const int L = i / np, pl = i - L * np;
+        const DSphereCold& c = sc.sphereCold[sc.light[L]];
+        const DFloat4 r = sc.planeRow[pl];
+        const float g = r.x * c.cx + r.y * c.cy + r.z * c.cz + r.w;
+        const float tol = 1.001f * c.radius + 1e-3f + 1e-5f * (__builtin_fabsf(r.x * c.cx) + __builtin_fabsf(r.y * c.cy) + __builtin_fabsf(r.z * c.cz) + __builtin_fabsf(r.w));
+        lps[i] = (sc.planesRigid && g > tol) ? 1.0f : ((sc.planesRigid && g < -tol) ? -1.0f : 0.0f);
+    }
+    lds.lightPlaneSide = lps;
+    DFloat4* cam4 = le4 + sc.nLights + ((sc.nLights * np + 3) >> 2);
     if (threadIdx.x == 0) {
         cam4[0] = DFloat4{sc.p1[0], sc.p1[1], sc.p1[2], 0.0f};
         cam4[1] = DFloat4{sc.dp2[0], sc.dp2[1], sc.dp2[2], 0.0f};
@@ -1116,6 +1148,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     const float invS = krcp(args.S);
 #endif
     uint32_t trips = 0;
+    int heldTrips = 0; // (wave-uniform) consecutive trips in which some lane wanted the light / BSDF blocks and they did not run
     for (;;) {
         trips++;
         KAJO_STAMP(4); // tail of the previous trip (path bookkeeping, loop back-edge)
@@ -1356,7 +1389,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         // Measured (profiles/r03_hold_sweep.txt): STRICT +7.5 % at 24-32 lanes; FAST nothing while its loop spilled scalar
         // registers (the two ballots cost what the blocks saved), +2.4 % at 20 lanes since it does not.
         const unsigned long long wantL = __ballot(sampleNext);
-        const bool runL = __builtin_popcountll(wantL) >= args.thrL || __ballot(mode == MODE_HOLD) != 0ull;
+        // (holdTrips: how many trips in a row the blocks may be put off while somebody wants them; 1 = no vertex waits twice)
+        const int wantCount = __builtin_popcountll(wantL);
+        const bool runL = wantCount >= args.thrL || heldTrips >= args.holdTrips;
+        heldTrips = (runL || wantCount == 0) ? 0 : heldTrips + 1;
         if (sampleNext && !runL)
             mode = MODE_HOLD;
         sampleNext = sampleNext && runL;
@@ -1426,6 +1462,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #if KAJO_STRICT
                         vLd = vLd + pendContrib;
 #else
+                        // (the product above stays a rounded value of its own, as in the kernels where it waits a trip for its
+                        // shadow ray: contracted into this sum it would round once -- FAST with and without lists must agree bit for bit)
+                        asm volatile("" : "+v"(pendContrib.x), "+v"(pendContrib.y), "+v"(pendContrib.z));
                         vE = vE + pendContrib;
 #endif
                     }
@@ -1640,4 +1679,28 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_RESOLVE_NAME(const float4
     }
     const int al = (int)(1.f * 255.f + .5f);
     dst[i] = ((uint32_t)al << 24) | ((uint32_t)out[0] << 16) | ((uint32_t)out[1] << 8) | (uint32_t)out[2];
+}
+
+// The same resolve straight from compact tile buffers (one owner's own, or `tileCount` gathered ones in rank order): the
+// composed whole frame -- W*H float4 written by kajo_compose and read back here -- is not needed to show an image.
+extern "C" __global__ void __launch_bounds__(256) KAJO_RESOLVE_TILES_NAME(const float4* gathered, TileMap map, float passes, uint32_t* dst)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= map.W || y >= map.H)
+        return;
+    int owner;
+    uint32_t slot;
+    kajoTileSlot(map, x, y, &owner, &slot);
+    const float4 a = gathered[(size_t)owner * map.slotsPerOwner + slot];
+    const float in[3] = {a.x, a.y, a.z};
+    int out[3];
+    for (int k = 0; k < 3; k++) {
+        float v = kdiv(in[k], passes);
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        v = kpow(v, 1 / 2.2f);
+        out[k] = (int)(v * 255.f + .5f);
+    }
+    const int al = (int)(1.f * 255.f + .5f);
+    dst[(size_t)y * map.W + x] = ((uint32_t)al << 24) | ((uint32_t)out[0] << 16) | ((uint32_t)out[1] << 8) | (uint32_t)out[2];
 }

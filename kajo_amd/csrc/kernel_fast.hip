@@ -10,5 +10,6 @@
 #define KAJO_KAT_SHADE_NAME kajo_kat_shade_fast
 #define KAJO_KAT_TRACE_NAME kajo_kat_trace_fast
 #define KAJO_RESOLVE_NAME kajo_resolve_fast
+#define KAJO_RESOLVE_TILES_NAME kajo_resolve_tiles_fast
 #include "integrator.inc.hip"
 #include "launch.inc.hip"

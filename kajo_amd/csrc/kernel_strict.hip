@@ -7,6 +7,7 @@
 #define KAJO_KAT_SHADE_NAME kajo_kat_shade_strict
 #define KAJO_KAT_TRACE_NAME kajo_kat_trace_strict
 #define KAJO_RESOLVE_NAME kajo_resolve_strict
+#define KAJO_RESOLVE_TILES_NAME kajo_resolve_tiles_strict
 #include "integrator.inc.hip"
 #include "launch.inc.hip"
 

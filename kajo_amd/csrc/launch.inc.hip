@@ -53,6 +53,14 @@ extern "C" int KAJO_CAT(KAJO_RESOLVE_NAME, _launch)(const void* frame, int count
     return (int)hipGetLastError();
 }
 
+extern "C" int KAJO_CAT(KAJO_RESOLVE_TILES_NAME, _launch)(const void* gathered, const TileMap* map, float passes, void* dst, void* stream)
+{
+    dim3 grid((map->W + 63) / 64, (map->H + 3) / 4), block(256);
+    hipLaunchKernelGGL(KAJO_RESOLVE_TILES_NAME, grid, block, 0, static_cast<hipStream_t>(stream), static_cast<const float4*>(gathered), *map, passes,
+                       static_cast<uint32_t*>(dst));
+    return (int)hipGetLastError();
+}
+
 extern "C" int KAJO_CAT(KAJO_KAT_SHADE_NAME, _launch)(const RenderArgs* args, unsigned grid, size_t ldsBytes, void* stream)
 {
     hipLaunchKernelGGL(KAJO_KAT_SHADE_NAME, dim3(grid), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), *args);

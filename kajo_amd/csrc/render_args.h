@@ -26,7 +26,8 @@ struct RenderArgs
     // Per-wave LDS (integrator.inc.hip renderBody): wave w of the workgroup owns perWaveBytes at perWaveOffset + w * perWaveBytes:
     // the mailbox of taken-over passes, 64 lanes x stealWindow x float4 (absent in the SPLIT kernels).
     uint32_t perWaveOffset, perWaveBytes;
-    int32_t thrL;                 // MODE_HOLD: the light / BSDF blocks run in a trip when this many lanes want them, or one has waited a trip
+    int32_t thrL;                 // MODE_HOLD: the light / BSDF blocks run in a trip when this many lanes want them, or when they
+    int32_t holdTrips;            // have been put off this many trips in a row (1: no vertex waits twice)
     // Launch-order feedback: blocks are dispatched in blockIdx order; the host sorts them by the cost the
     // previous launch measured (longest first) so that the launch does not end on its most expensive
     // workgroups. Pure scheduling: the buffer slot of a pixel does not depend on it.

@@ -300,11 +300,15 @@ void buildShadowLists(const KajoScene& s, StagedScene& out, bool wanted)
     const int n = s.nSpheres, nL = (int)out.light.size();
     if (!wanted || !out.gridEnabled || !out.allTranslated || nL == 0)
         return;
-    int N = 32; // bins per cube-face axis: 6144 direction bins per light (1000 spheres / 16 lights: 7.8 candidate spheres per query
-                // and 2.2 MB of lists; 16: 15.1 and 0.9 MB; 64: 5.1 and 6.8 MB -- the tube of radius r_light alone holds ~4)
-    KAJO_TUNE_INT("KAJO_SHADOW_BINS", 2, 64, N);
+    // bins per cube-face axis. 1000 spheres / 16 lights: 16 -> 15.1 candidate spheres per query, 0.9 MB of lists, 1.64 G paths/s;
+    // 32 -> 7.8, 2.2 MB, 2.35 G; 64 -> 5.1, 6.8 MB, 2.74 G; 96 and 128 -> 2.3 G again (the lists fall out of the L2). The tube of
+    // radius r_light around the segment alone holds ~4 spheres. Scenes of very many lights get coarser bins (4 M bins in all).
+    int N = 64;
+    while (N > 8 && (size_t)nL * 6 * N * N > ((size_t)1 << 22))
+        N /= 2;
+    KAJO_TUNE_INT("KAJO_SHADOW_BINS", 2, 128, N);
     const size_t binsPerLight = (size_t)6 * N * N;
-    if ((size_t)nL * binsPerLight > ((size_t)1 << 22))
+    if ((size_t)nL * binsPerLight > ((size_t)1 << 23))
         return;
     // scene extent: sphere bounds and the camera
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};

@@ -4,6 +4,7 @@
 #include <rccl/rccl.h>
 
 #include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -111,8 +112,21 @@ struct Scheduler::Impl
         pod.spheres = spheres.data();
         pod.planes = planes.data();
 
+        if (opt.gpus == 0) {
+            // The reference's driver has no flag for it (renderer/Main.cpp:104-120): the backend takes the node as it finds it,
+            // as cpu::Scheduler takes every core (renderer/cpu/Scheduler.cpp:17-24). KAJO_HIP_GPUS caps it.
+            int visible = 0;
+            checkHip(hipGetDeviceCount(&visible), "hipGetDeviceCount");
+            opt.gpus = visible;
+            if (const char* e = std::getenv("KAJO_HIP_GPUS")) {
+                const int want = std::atoi(e);
+                if (want < 1 || want > visible)
+                    throw std::runtime_error("hip::Scheduler: KAJO_HIP_GPUS must be between 1 and the number of visible GPUs");
+                opt.gpus = want;
+            }
+        }
         if (opt.gpus < 1)
-            throw std::runtime_error("hip::Scheduler: gpus must be >= 1");
+            throw std::runtime_error("hip::Scheduler: no GPU visible (this backend has no CPU path)");
         if (opt.sameDevice && opt.gather != Options::Copy)
             throw std::runtime_error("hip::Scheduler: sameDevice needs gather = Copy (RCCL wants one rank per device)");
         for (int g = 0; g < opt.gpus; g++) {
@@ -215,6 +229,8 @@ void Scheduler::run()
     const std::thread::id self = std::this_thread::get_id();
     const auto t0 = std::chrono::steady_clock::now();
     int done = 0;
+    std::vector<double> batchMs;
+    std::vector<int> batchPasses;
     // Passes between two refreshes. Fusing passes into one launch evens out the lanes' trip counts (38 G paths/s at
     // 16 per launch against 30 at one), so headless runs take all that is left and a live preview
     // gets as many as fit a 30 Hz refresh, from the measured time per pass.
@@ -243,7 +259,10 @@ void Scheduler::run()
         done += now;
         d.gatherAndCompose();
         check(kajo_hip_resolve_argb8(d.handles[0], d.image->pixels.get()), "kajo_hip_resolve_argb8");
-        const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count() / now;
+        const double batchWall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
+        batchMs.push_back(batchWall);
+        batchPasses.push_back(now);
+        const double ms = batchWall / now;
         msPerPass = msPerPass <= 0.0 ? ms : 0.75 * msPerPass + 0.25 * ms;
         if (d.preview)
             for (int p = done - now + 1; p <= done; p++)
@@ -252,6 +271,9 @@ void Scheduler::run()
 
     d.stats = Statistics();
     d.stats.passes = done;
+    d.stats.gpus = o.gpus;
+    d.stats.batchMs = batchMs;
+    d.stats.batchPasses = batchPasses;
     d.stats.wallSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     for (kajo_hip_t h : d.handles) {
         KajoCounters c;

@@ -12,6 +12,7 @@
 
 #include <cstdint>
 #include <memory>
+#include <vector>
 
 #include "Scheduler.h"
 
@@ -35,7 +36,11 @@ struct Options
                                   // (16 when there is no preview: the reference never stops by itself)
     int passesPerUpdate = 0;      // passes rendered between two image/preview refreshes; 0 = automatic: everything that is
                                   // left (up to 16) without a preview, as many as fit a 30 Hz refresh with one
-    int gpus = 1;                 // devices 0 .. gpus-1
+    int gpus = 0;                 // devices 0 .. gpus-1; 0 = every GPU the HIP runtime shows (hipGetDeviceCount), or the
+                                  // number in the environment variable KAJO_HIP_GPUS when that is set -- what the
+                                  // three-argument constructor (the form renderer/Main.cpp:135-142 calls) uses, so that
+                                  // `renderer -r hip scene.json` tiles the frame over the whole node with no flag the
+                                  // reference does not have
     bool strict = false;          // STRICT numerics (bit-identical to the CPU oracle)
     bool counters = false;
     enum Gather { Rccl, Copy } gather = Rccl; // Copy: hipMemcpyAsync instead of RCCL (also lets
@@ -51,6 +56,9 @@ struct Statistics
     unsigned long long paths = 0, traversals = 0, vertices = 0, laneSlots = 0;
     double kernelMs = 0;   // max over GPUs of the summed render-kernel time
     double wallSeconds = 0;
+    int gpus = 0;          // tile owners the frame was dealt to
+    std::vector<double> batchMs; // wall time of every refresh: render launch .. Image::pixels filled (host), in run() order
+    std::vector<int> batchPasses;
 };
 
 class Scheduler : public ::Scheduler

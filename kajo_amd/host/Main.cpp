@@ -21,7 +21,9 @@ int main(int argc, char** argv)
     int width = 640, height = 480;
     hip::Options opt;
     opt.passes = 16;
-    bool verbose = false, json = false;
+    opt.gpus = 1;
+    std::string podPath;
+    bool verbose = false, json = false, threeArg = false;
     for (size_t i = 1; i < args.size(); i++) {
         bool more = i + 1 < args.size();
         const std::string& a = args[i];
@@ -34,7 +36,11 @@ int main(int argc, char** argv)
                         "    --passes N      passes to render (16)\n"
                         "    --bounces N     depth limit (8)\n"
                         "    --seed N        stream seed (236367)\n"
-                        "    --gpus N        GPUs to tile the frame over (1)\n"
+                        "    --gpus N        GPUs to tile the frame over (1; 0 = every visible GPU, or KAJO_HIP_GPUS)\n"
+                        "    --three-arg     construct the backend exactly as a Kajo checkout does, hip::Scheduler(scene, image, preview):\n"
+                        "                    reference constants, every visible GPU (or KAJO_HIP_GPUS), until the preview closes (--passes)\n"
+                        "    --scene-pod F   read the scene as a flat binary image of scene::Scene (int32 nSpheres, nPlanes; background 4 f32;\n"
+                        "                    view 16; projection 16; spheres 39 f32 each; planes 38 f32 each) instead of a JSON file\n"
                         "    --batch N       passes per image refresh (0 = automatic: 16 headless, a 30 Hz refresh with a preview)\n"
                         "    --strict        strict numerics\n"
                         "    --gather MODE   rccl | copy (multi-GPU gather transport)\n"
@@ -59,6 +65,8 @@ int main(int argc, char** argv)
         else if (a == "--gather" && more) opt.gather = args[++i] == "copy" ? hip::Options::Copy : hip::Options::Rccl;
         else if (a == "--same-device") { opt.sameDevice = true; opt.gather = hip::Options::Copy; }
         else if (a == "--force-gather") opt.forceGather = true;
+        else if (a == "--three-arg") threeArg = true;
+        else if (a == "--scene-pod" && more) podPath = args[++i];
         else if (a == "-o" && more) out = args[++i];
         else if (a == "--raw" && more) rawOut = args[++i];
         else if (a == "--json") json = true;
@@ -71,7 +79,28 @@ int main(int argc, char** argv)
     }
 
     scene::Scene scene;
-    if (scenePath.empty())
+    if (!podPath.empty()) {
+        // a parsed scene as the tests' fixtures hold it (tests/golden/scenes.npz): the records have scene::Scene's own layout
+        std::ifstream f(podPath, std::ios::binary);
+        int32_t counts[2] = {0, 0};
+        f.read(reinterpret_cast<char*>(counts), sizeof counts);
+        if (!f || counts[0] < 0 || counts[1] < 0 || counts[0] > (1 << 20) || counts[1] > (1 << 20)) {
+            std::cerr << "Failed to read scene image " << podPath << std::endl;
+            return 1;
+        }
+        static_assert(sizeof(scene::Sphere) == 39 * sizeof(float) && sizeof(scene::Plane) == 38 * sizeof(float), "records are packed floats");
+        f.read(reinterpret_cast<char*>(&scene.backgroundColor), 16);
+        f.read(reinterpret_cast<char*>(&scene.camera.transform), 64);
+        f.read(reinterpret_cast<char*>(&scene.camera.projection), 64);
+        scene.spheres.resize(counts[0]);
+        scene.planes.resize(counts[1]);
+        f.read(reinterpret_cast<char*>(scene.spheres.data()), (std::streamsize)(sizeof(scene::Sphere) * scene.spheres.size()));
+        f.read(reinterpret_cast<char*>(scene.planes.data()), (std::streamsize)(sizeof(scene::Plane) * scene.planes.size()));
+        if (!f) {
+            std::cerr << "Failed to read scene image " << podPath << std::endl;
+            return 1;
+        }
+    } else if (scenePath.empty())
         scene::buildTestScene(scene);
     else if (!scene::Parser::load(scene, scenePath, static_cast<float>(width) / height)) {
         std::cerr << "Failed to parse scene from " << scenePath << std::endl;
@@ -86,7 +115,8 @@ int main(int argc, char** argv)
     opt.counters = json;
     try {
         if (rendererName == "hip") {
-            hipScheduler = new hip::Scheduler(scene, image.get(), preview.get(), opt);
+            // (--three-arg: the statement integration/apply_to_kajo.sh adds to renderer/Main.cpp:135-142, word for word)
+            hipScheduler = threeArg ? new hip::Scheduler(scene, image.get(), preview.get()) : new hip::Scheduler(scene, image.get(), preview.get(), opt);
             scheduler.reset(hipScheduler);
         } else {
             std::cerr << "Unknown renderer: " << rendererName << std::endl;
@@ -108,9 +138,15 @@ int main(int argc, char** argv)
     if (json) {
         const hip::Statistics& s = hipScheduler->statistics();
         std::printf("{\"width\": %d, \"height\": %d, \"passes\": %d, \"gpus\": %d, \"paths\": %llu, \"traversals\": %llu, "
-                    "\"vertices\": %llu, \"wall_s\": %.6f, \"kernel_ms\": %.3f, \"msamples_per_s\": %.2f}\n",
-                    width, height, s.passes, opt.gpus, s.paths, s.traversals, s.vertices, s.wallSeconds, s.kernelMs,
+                    "\"vertices\": %llu, \"wall_s\": %.6f, \"kernel_ms\": %.3f, \"msamples_per_s\": %.2f, \"batch_ms\": [",
+                    width, height, s.passes, s.gpus, s.paths, s.traversals, s.vertices, s.wallSeconds, s.kernelMs,
                     s.paths / s.wallSeconds / 1e6);
+        for (size_t i = 0; i < s.batchMs.size(); i++)
+            std::printf("%s%.4f", i ? ", " : "", s.batchMs[i]);
+        std::printf("], \"batch_passes\": [");
+        for (size_t i = 0; i < s.batchPasses.size(); i++)
+            std::printf("%s%d", i ? ", " : "", s.batchPasses[i]);
+        std::printf("]}\n");
     }
     return 0;
 }

@@ -125,6 +125,14 @@ class Scene:
         s.planes = C.cast(self.planes.ctypes.data, C.POINTER(KajoPlane))
         return s
 
+    def write_pod(self, path: str) -> None:
+        """The flat binary image kajo_render --scene-pod reads (kajo_amd/host/Main.cpp): int32 nSpheres, nPlanes; background;
+        view; projection; sphere records (39 f32); plane records (38 f32) -- scene::Scene's own record layout."""
+        with open(path, "wb") as f:
+            f.write(np.array([self.n_spheres, self.n_planes], np.int32).tobytes())
+            for a in (self.background, self.view, self.proj, self.spheres, self.planes):
+                f.write(np.ascontiguousarray(a, np.float32).tobytes())
+
     def with_aspect(self, aspect: float) -> "Scene":
         """Same scene, projection rebuilt for another aspect ratio. glm::perspective
         (gtc/matrix_transform.inl:223-245) only puts the aspect into element [0][0]:

@@ -198,3 +198,40 @@ def test_set_pass_count_continues_a_restored_session(scenes):
         assert np.array_equal(got.view(np.uint32), whole.view(np.uint32))
         assert np.array_equal(b.argb8(), px_whole)
         assert b.counters()["passes"] == 5
+
+
+def test_resolve_straight_from_tile_buffers(scenes):
+    """kajo_hip_resolve_gathered_argb8_device (compose + resolve in one pass over the tile buffers, what rank 0 of a multi-GPU
+    frame and every one-GPU refresh run) gives the image of kajo_compose followed by the whole-frame resolve, bit for bit:
+    one owner, and three owners on one device whose buffers are laid side by side as a gather leaves them; ragged frame."""
+    import ctypes as C
+    import torch
+    from kajo_amd import capi
+    from bench import DevicePtr
+    sc = scenes["spheres_a169"]
+    W, H = 200, 77
+    L = capi.lib()
+    for strict in (False, True):
+        with HipRenderer(sc, W, H, strict=strict) as r:
+            r.render(3).wait()
+            fused = r.argb8()            # no composed frame yet: straight from the tile buffer
+            r.radiance()                 # composes the float frame
+            two_pass = r.argb8()         # ... which the whole-frame resolve then reads
+        assert np.array_equal(fused, two_pass)
+        owners = [HipRenderer(sc, W, H, strict=strict, tile_index=k, tile_count=3) for k in range(3)]
+        parts = []
+        for o in owners:
+            o.render(3).wait()
+            ptr, nbytes = o.tile_buffer()
+            parts.append(torch.as_tensor(DevicePtr(ptr, nbytes // 4), device="cuda").clone())
+        gathered = torch.cat(parts)
+        out = torch.empty(W * H, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()  # (the handles run on streams of their own)
+        capi.check(L.kajo_hip_resolve_gathered_argb8_device(owners[0]._h, C.c_void_p(gathered.data_ptr()), C.c_void_p(out.data_ptr())))
+        owners[0].wait()
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32).reshape(H, W), fused)
+        with pytest.raises(Exception, match="gathered"):
+            capi.check(L.kajo_hip_resolve_gathered_argb8_device(owners[1]._h, None, C.c_void_p(out.data_ptr())))
+        for o in owners:
+            o.close()

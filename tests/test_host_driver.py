@@ -82,6 +82,34 @@ def test_rccl_gather_call_sequence_on_one_gpu(tmp_path):
     assert np.array_equal(acc.view(np.uint32), base.view(np.uint32))
 
 
+def test_three_argument_constructor_takes_the_whole_node(tmp_path, scenes):
+    """The form a Kajo checkout constructs -- new hip::Scheduler(scene, image.get(), preview.get()), renderer/Main.cpp:135-142 as
+    integration/apply_to_kajo.sh patches it -- has no options: it deals the frame to EVERY visible GPU (one here; KAJO_HIP_GPUS
+    caps it), gathers with RCCL, and runs until the preview closes. Same frame as the C ABI gives directly; the scene travels
+    as a flat image of scene::Scene (--scene-pod), so the JSON loader is not part of what is compared."""
+    import torch
+    sc = scenes["spheres_a169"]
+    pod = str(tmp_path / "scene.pod")
+    sc.write_pod(pod)
+    out, raw = str(tmp_path / "o.png"), str(tmp_path / "o.raw")
+    cmd = [BIN, "-w", "160", "-h", "90", "-r", "hip", "--passes", "3", "--three-arg", "-o", out, "--raw", raw, "--json", "--scene-pod", pod]
+    env = {k: v for k, v in os.environ.items() if k != "KAJO_HIP_GPUS"}
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=env)
+    assert p.returncode == 0, p.stderr
+    stats = json.loads(p.stdout.strip().splitlines()[-1])
+    # (the form has no pass budget: it refreshes until the "window" closes -- the headless preview does after 3 passes -- and a
+    # refresh renders as many passes as fit a 30 Hz frame, so it may overshoot by part of a batch, as the reference's loop does)
+    assert stats["gpus"] == torch.cuda.device_count() and 3 <= stats["passes"] <= 3 + 16
+    acc = np.fromfile(raw, np.float32).reshape(90, 160, 4)
+    with HipRenderer(sc, 160, 90) as r:
+        want = r.render(stats["passes"]).radiance()
+    assert np.array_equal(acc.view(np.uint32), want.view(np.uint32))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=dict(env, KAJO_HIP_GPUS="1"))
+    assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["gpus"] == 1
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=dict(env, KAJO_HIP_GPUS=str(torch.cuda.device_count() + 1)))
+    assert p.returncode == 2 and "KAJO_HIP_GPUS" in p.stderr
+
+
 def test_driver_matches_oracle_strict(tmp_path):
     # the C++ host path end to end (loader -> hip::Scheduler -> C ABI -> STRICT kernels) against the CPU oracle itself
     from oraclelib import OracleLib, available

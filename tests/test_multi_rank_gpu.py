@@ -36,6 +36,7 @@ def test_bench_two_ranks_on_one_gpu_gloo_rehearsal():
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and "3840x2160" in out["config"]["workload"]
     assert out["config"]["world_size_seen_by_backend"] == 2
     mg = out["multi_gpu"]
-    assert mg["frame_bit_identical_to_one_gpu"] is True
+    assert mg["frame_bit_identical_to_one_gpu"] is True and mg["argb8_bit_identical_to_one_gpu"] is True
+    assert "one kernel" in mg["compose_resolve"]  # rank 0 resolves straight from the gathered tile buffers
     assert len(mg["kernel_ms_per_step_by_rank"]) == 2 and min(mg["kernel_ms_per_step_by_rank"]) > 0
     assert sum(mg["paths_per_step_by_rank"]) == out["config"]["paths_per_step"]

@@ -16,7 +16,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"D": "KAJO_STASH_DEPTH", "R": "KAJO_RING_SLOTS", "L": "KAJO_THR_L", "S": "KAJO_THR_STALL", "W": "KAJO_STEAL_WINDOW",
-        "B": "KAJO_WAVES_PER_BLOCK", "X": "KAJO_LDS_EXTRA"}
+        "B": "KAJO_WAVES_PER_BLOCK", "X": "KAJO_LDS_EXTRA", "N": "KAJO_SHADOW_BINS", "G": "KAJO_GRID_LDS_LIMIT", "H": "KAJO_HOLD_TRIPS"}
 
 
 def child(workload, mode, configs):

@@ -425,6 +425,12 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     // waited a trip; 1 = every trip. Large scenes run them every trip (16 lights: most lanes are in them anyway).
     h->thrL = big ? 1 : (h->strict() ? 28 : 20);
     h->holdTrips = 1;
+    if (!big && h->strict()) {
+        // the STRICT loop of small scenes walks its shadow rays inside the light loop (KAJO_INLINE_SHADOW): a heavier block, worth
+        // waiting longer for (spheres.json: 19.15 G paths/s at 28 lanes / one trip, 19.85 at 44 / two; three lights: 11.6 -> 13.4 at 48 / three)
+        h->thrL = v.nLights > 1 ? 48 : 44;
+        h->holdTrips = v.nLights > 1 ? 3 : 2;
+    }
     if (st.shadowEnabled) {
         // Large scenes with visibility lists: the light loop runs to its end inside one trip (16 lights: ~10 rounds of light
         // sample + shadow query) and is the expensive block of a trip, with a third of the lanes in it. It runs when 48 lanes

@@ -1,5 +1,8 @@
 // STRICT numerics: bit-identical to the CPU oracle. Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #define KAJO_STRICT 1
+#ifndef KAJO_INLINE_SHADOW
+#define KAJO_INLINE_SHADOW 1 // small scenes answer shadow rays inside the light loop (integrator.inc.hip)
+#endif
 #define KAJO_KERNEL_NAME kajo_render_strict
 #define KAJO_KERNEL_NAME_BIG kajo_render_strict_big
 #define KAJO_KERNEL_NAME_BIGLIST kajo_render_strict_biglist

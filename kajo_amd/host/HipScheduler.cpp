@@ -70,6 +70,7 @@ struct Scheduler::Impl
     std::vector<hipStream_t> streams; // one per owner, shared with its handle
     std::vector<ncclComm_t> comms;
     void* gathered = nullptr;         // on device 0: gpus consecutive tile buffers
+    void* argbDevice = nullptr;       // on device 0: the resolved image of a gathered frame, before it goes to Image::pixels
     size_t tileBytes = 0;
     Statistics stats;
 
@@ -87,6 +88,8 @@ struct Scheduler::Impl
             (void)hipSetDevice(devices.empty() ? 0 : devices[0]);
             (void)hipFree(gathered);
         }
+        if (argbDevice)
+            (void)hipFree(argbDevice);
     }
 
     void create(const scene::Scene& s)
@@ -150,6 +153,7 @@ struct Scheduler::Impl
             check(kajo_hip_tile_buffer(handles[0], &ptr, &tileBytes), "kajo_hip_tile_buffer");
             checkHip(hipSetDevice(devices[0]), "hipSetDevice");
             checkHip(hipMalloc(&gathered, tileBytes * opt.gpus), "hipMalloc(gather buffer)");
+            checkHip(hipMalloc(&argbDevice, (size_t)image->width * image->height * 4), "hipMalloc(image)");
             // one stream per owner carries both its render kernels and its share of the gather
             for (int g = 0; g < opt.gpus; g++) {
                 checkHip(hipSetDevice(devices[g]), "hipSetDevice");
@@ -165,11 +169,15 @@ struct Scheduler::Impl
         }
     }
 
-    // One exchange per displayed frame: every owner's tile buffer -> GPU 0
-    void gatherAndCompose()
+    // One exchange per displayed frame: every owner's tile buffer -> GPU 0; then the image straight
+    // from the gathered buffers into Image::pixels (the float frame is composed only when readRadiance() asks for it).
+    void gatherAndResolve()
     {
-        if (opt.gpus == 1 && !opt.forceGather)
-            return; // single owner: the library composes from its own tiles
+        if (opt.gpus == 1 && !opt.forceGather) {
+            // single owner: the library resolves from its own tile buffer
+            check(kajo_hip_resolve_argb8(handles[0], image->pixels.get()), "kajo_hip_resolve_argb8");
+            return;
+        }
         const size_t count = tileBytes / sizeof(float);
         if (opt.gather == Options::Rccl) {
             checkNccl(ncclGroupStart(), "ncclGroupStart");
@@ -193,8 +201,14 @@ struct Scheduler::Impl
                          "hipMemcpyAsync(gather)");
             }
         }
-        check(kajo_hip_compose(handles[0], gathered), "kajo_hip_compose");
+        composed = false;
+        check(kajo_hip_resolve_gathered_argb8_device(handles[0], gathered, argbDevice), "kajo_hip_resolve_gathered_argb8_device");
+        checkHip(hipSetDevice(devices[0]), "hipSetDevice");
+        checkHip(hipMemcpyAsync(image->pixels.get(), argbDevice, (size_t)image->width * image->height * 4, hipMemcpyDeviceToHost, streams[0]),
+                 "hipMemcpyAsync(image)");
+        checkHip(hipStreamSynchronize(streams[0]), "hipStreamSynchronize");
     }
+    bool composed = false;
 };
 
 Scheduler::Scheduler(const scene::Scene& scene, Image* image, Preview* preview): Scheduler(scene, image, preview, Options())
@@ -218,7 +232,12 @@ const Statistics& Scheduler::statistics() const
 
 void Scheduler::readRadiance(float* dst)
 {
-    check(kajo_hip_read_radiance(m_impl->handles[0], dst), "kajo_hip_read_radiance");
+    Impl& d = *m_impl;
+    if (d.gathered && !d.composed) { // several owners (or the forced gather): the whole float frame from the last gather
+        check(kajo_hip_compose(d.handles[0], d.gathered), "kajo_hip_compose");
+        d.composed = true;
+    }
+    check(kajo_hip_read_radiance(d.handles[0], dst), "kajo_hip_read_radiance");
 }
 
 void Scheduler::run()
@@ -257,8 +276,7 @@ void Scheduler::run()
         for (kajo_hip_t h : d.handles)
             check(kajo_hip_wait(h), "kajo_hip_wait");
         done += now;
-        d.gatherAndCompose();
-        check(kajo_hip_resolve_argb8(d.handles[0], d.image->pixels.get()), "kajo_hip_resolve_argb8");
+        d.gatherAndResolve();
         const double batchWall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
         batchMs.push_back(batchWall);
         batchPasses.push_back(now);

@@ -99,7 +99,7 @@ def main():
         env = dict(os.environ)
         if lib:
             env["KAJO_HIP_LIB"] = os.path.join(ROOT, lib) if not os.path.isabs(lib) else lib
-        cfgs = configs if lib is None else [""]
+        cfgs = configs  # (a --lib built without -DKAJO_TUNING ignores the knobs)
         if lib is None and any(cfgs):  # knobs are read by the tools' twin only (kajo_amd/csrc/tuning.h); the product library ignores them
             env["KAJO_HIP_LIB"] = os.path.join(ROOT, "kajo_amd", "libkajo_hip_tune.so")
         subprocess.run([sys.executable, os.path.abspath(__file__), "--child", workload, mode, json.dumps(cfgs)], env=env, check=False)

@@ -154,6 +154,29 @@ def test_shadow_lists_equal_the_grid_walk(O, scenes):
             assert a["vertices"] == b["vertices"]
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4])
+def test_shadow_lists_on_adversarial_geometry(O, scenes, seed):
+    """Overlapping and nested spheres, big lights, a light cut by the ceiling plane, a light touching a sphere, 1 cm spheres
+    (tests/test_shadow_lists_cpu.py adversarial_scene): STRICT with lists = STRICT through the grid = the oracle's every-object
+    walk, bit for bit; FAST with lists = FAST through the grid."""
+    from kajo_amd import capi
+    from test_shadow_lists_cpu import adversarial_scene
+    sc = adversarial_scene(scenes["spheres_a169"], seed)
+    W, H, S, passes = 96, 54, 9, 2
+    want = O.create(sc, math=1).render(W, H, S=S, passes=passes, seed=SEED, depth_limit=8)
+    got = {}
+    for strict in (True, False):
+        for flags in (0, capi.KAJO_FLAG_NO_SHADOW_LISTS):
+            with HipRenderer(sc, W, H, spp=S, seed=SEED, strict=strict, counters=True, flags=flags) as r:
+                got[strict, flags] = (r.render(passes).radiance(), r.counters())
+    assert got[True, 0][1]["shadowQueries"] > 0 and got[True, capi.KAJO_FLAG_NO_SHADOW_LISTS][1]["shadowQueries"] == 0
+    for flags in (0, capi.KAJO_FLAG_NO_SHADOW_LISTS):
+        g = got[True, flags][0][..., :3]
+        assert ((g.view(np.uint32) == want[..., :3].view(np.uint32)) | (np.isnan(g) & np.isnan(want[..., :3]))).all(), (seed, flags)
+    a, b = got[False, 0][0], got[False, capi.KAJO_FLAG_NO_SHADOW_LISTS][0]
+    assert ((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all(), seed
+
+
 def test_strict_passes_split_and_reset(scenes):
     sc = scenes["spheres_a1"]
     with HipRenderer(sc, 40, 24, strict=True, passes_per_launch=1) as a, HipRenderer(sc, 40, 24, strict=True) as b:

@@ -76,3 +76,65 @@ def test_every_blocker_is_a_candidate(scenes, n_spheres, n_lights, seed):
 
 def test_small_scenes_get_no_lists(scenes):
     assert stage_shadow_lists(scenes["spheres_a169"]) is None  # 5 spheres: no grid, every object is walked
+
+
+def adversarial_scene(base, seed, n=90, n_lights=5):
+    """Geometry the lists' margins have to survive: overlapping and nested spheres, big lights, lights that touch or contain
+    other spheres, spheres cut by the room's planes, a light hugging a wall, tiny spheres; all pure translations (balls)."""
+    from kajo_amd.scene import Scene, material, sphere_record, translate
+    rng = np.random.default_rng(seed)
+    lin = lambda c: np.float32(c) ** np.float32(2.2)
+    recs = []
+    for k in range(n):
+        c = np.array([rng.uniform(-4, 8), rng.uniform(-1.9, 0.95), rng.uniform(-1.8, 5)])
+        r = float(rng.choice([0.01, 0.05, 0.2, 0.5, 0.9], p=[.1, .3, .3, .2, .1]))
+        if k % 7 == 3 and recs:  # nested in / overlapping the previous one
+            c = recs[-1][12:15] + rng.normal(size=3) * 0.1
+        col = [lin(.2 + .6 * rng.random()) for _ in range(3)]
+        m = material(diffuse=col) if k % 2 == 0 else material(specular=col, exponent=float(rng.choice([0, 10, 100])))
+        recs.append(sphere_record(translate(*c), m, r))
+    for k in range(n_lights):
+        c = [rng.uniform(-3, 7), rng.uniform(-1.9, 0.5), rng.uniform(-1, 4)]
+        r = float(rng.choice([0.05, 0.3, 0.8]))
+        if k == 0:
+            c, r = [2.0, -1.95, 1.0], 0.3  # cut by the ceiling plane (y = -2)
+        if k == 1 and recs:
+            c, r = list(recs[0][12:15] + np.array([recs[0][38] + 0.1, 0, 0])), 0.1  # touching sphere 0
+        recs.append(sphere_record(translate(*c), material(emission=[lin(6.0)] * 3), r))
+    return Scene(base.background, base.view, base.proj, np.stack(recs), base.planes, "adversarial%d" % seed)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_blockers_are_candidates_on_adversarial_geometry(scenes, seed):
+    sc = adversarial_scene(scenes["spheres_a169"], seed)
+    L = stage_shadow_lists(sc)
+    assert L is not None
+    n, start, key, index = L["n"], L["start"], L["key"], L["index"]
+    h = OracleLib("oracle").create(sc, 1)
+    rng = np.random.default_rng(seed)
+    m = 5000
+    org = np.stack([rng.uniform(-3, 9, m), rng.uniform(-1.8, 0.9, m), rng.uniform(-1.5, 4.5, m)], 1).astype(np.float32)
+    d = rng.normal(size=(m, 3)).astype(np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    hit = h.trace(org, d)
+    P = hit["position"][hit["idx"] > 0]
+    np_, centre, radius = sc.n_planes, sc.spheres[:, 12:15], sc.spheres[:, 38]
+    checked = 0
+    for k, sl in enumerate(L["lights"]):
+        C, r = centre[sl], radius[sl]
+        q = rng.normal(size=P.shape).astype(np.float32)
+        q *= (r * rng.random((len(P), 1)) ** (1 / 3) / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+        l = (C + q - P).astype(np.float32)
+        l /= np.linalg.norm(l, axis=1, keepdims=True).astype(np.float32)
+        O = (P + l * np.float32(1e-3)).astype(np.float32)
+        got = h.trace(O, l)["idx"]
+        u = (O - C).astype(np.float32)
+        bins = k * 6 * n * n + bin_of(u, n)
+        reach = np.maximum(np.sqrt((u ** 2).sum(1)), r) * np.float32(1.000001)
+        # also: the light itself must be hit along such a ray whenever the walk says it is the closest hit (nothing to check
+        # in the lists), and any OTHER sphere that is the closest hit must be listed
+        for j in np.nonzero((got > np_) & (got != np_ + 1 + sl))[0]:
+            lo, hi = start[bins[j]], start[bins[j] + 1]
+            assert got[j] - 1 - np_ in index[lo:hi][key[lo:hi] <= reach[j]], (seed, k, j)
+            checked += 1
+    assert checked > 500

@@ -1,6 +1,6 @@
 """Experiments kept for their evidence, built apart from the product (`make -C kajo_amd/csrc experiments`):
 kajo_amd/libkajo_hip_r02.so (round 2's kernels, with the cooperative-traversal `_coop` variants, KAJO_FLAG_COOP) and
-kajo_amd/libkajo_hip_exp.so (the product source + deferred light/BSDF sampling, KAJO_FLAG_DEFERRED). The shipped libkajo_hip.so
+kajo_amd/libkajo_hip_exp.so (round 3's source + deferred light/BSDF sampling, KAJO_FLAG_DEFERRED; rebuilt from the git history). The shipped libkajo_hip.so
 contains neither and refuses both flags; these tests load an experiment library in a child process (KAJO_HIP_LIB)."""
 import os
 import subprocess
@@ -129,8 +129,8 @@ DEFERRED = textwrap.dedent("""
 def test_deferred_shading_is_result_identical():
     """KAJO_FLAG_DEFERRED (round 3): surviving vertices are parked in an LDS stash and the light / BSDF blocks
     run only in trips where enough lanes have one; paths of a pixel complete out of order and are retired in sample order through a
-    ring. STRICT stays the oracle bit for bit, FAST stays the product's FAST bit for bit, for several stash / ring / threshold
-    settings. Measured slower (the stash costs occupancy, and throughput follows waves per SIMD); not shipped."""
+    ring. STRICT stays the oracle bit for bit for several stash / ring / threshold settings; FAST stays within SURVEY section
+    8c's frame tolerances of the product's FAST (the same formulas compiled in another loop: contraction differs). Measured slower (the stash costs occupancy, and throughput follows waves per SIMD); not shipped."""
     env = dict(os.environ, KAJO_HIP_LIB=EXP)
     p = subprocess.run([sys.executable, "-c", DEFERRED], env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0 and "deferred ok" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]

@@ -484,7 +484,10 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
 // arithmetic; the walk's acceptance (Raytracer.cpp:115: reject only t > max, objects in scene order, so the closest wins and
 // among equal distances the later object) is applied in its order-independent form: something beats the light iff its
 // distance is smaller, or equal with a later index. Planes precede every sphere, so a plane must be strictly closer.
-KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, int si, F3 O, F3 d)
+// The part of the query every lane does for its own ray: the light itself and the planes. false: the light is not hit at all, or a
+// plane lies in front of it. `keyL`: the light's distance in the form the item tests compare against (STRICT: the float ts; FAST: its
+// bit pattern, trace()).
+KDEV bool lightReachedHead(const DSceneView& sc, const LdsScene& lds, int lightK, int si, F3 O, F3 d, uint32_t& keyL)
 {
     const int np = sc.nPlanes;
     const float aT = dot(d, d);
@@ -492,6 +495,7 @@ KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, in
     float tsL, thL;
     if (!sphereCandidate(sc, lds, si, O, d, aT, 0.0f, tsL, thL) || tsL < 0.0f)
         return false;
+    keyL = __builtin_bit_cast(uint32_t, tsL);
     // A plane that has the ray's origin AND the light's whole ball strictly on one side (by margins far above the rounding of
     // these sums) is crossed, if at all, behind the origin or beyond the ball: its test cannot come out "hit before the light".
     // The rays of a wave mostly agree on that (a room: everything is inside), so the rest of the test is skipped per wave.
@@ -508,8 +512,7 @@ KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, in
         float ts = t * det;
         blocked = blocked || (!(__builtin_fabsf(denom) < kFltEpsilon) && !(t < 0.0f) && !(ts < 0.0f) && ts < tsL);
     }
-    if (blocked)
-        return false;
+    return !blocked;
 #else
     const float iaT = krcp(aT);
     uint32_t kL;
@@ -522,6 +525,7 @@ KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, in
         const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
         kL = klo < khi ? klo : khi; // the smaller non-negative root; a negative root or NaN sorts above +inf (trace())
     }
+    keyL = kL;
     if (kL > 0x7f800000u)
         return false;
     const float tolO = 1e-3f + 1e-5f * (__builtin_fabsf(O.x) + __builtin_fabsf(O.y) + __builtin_fabsf(O.z)); // (see the STRICT twin above)
@@ -536,61 +540,51 @@ KDEV bool lightReached(const DSceneView& sc, const LdsScene& lds, int lightK, in
         const uint32_t kt = __builtin_bit_cast(uint32_t, __builtin_fmaf(-oy, krcp(denom), 0.0f));
         blocked = blocked || (!(__builtin_fabsf(denom) < kFltEpsilon) && kt < kL);
     }
-    if (blocked)
-        return false;
+    return !blocked;
 #endif
-    // the bin of u = O - C on the light's cube map, and how far from C the ray reaches
-    const DSphereCold& lc = lds.lightCold[lightK];
+}
+
+// Does sphere i lie in front of light `si` along the ray? The closest-hit walk's own sphere arithmetic; "in front" by the walk's
+// rule in its order-independent form (closer, or as close with a later index).
+KDEV bool shadowItemBlocks(const DSceneView& sc, const LdsScene& lds, int i, int si, F3 O, F3 d, float aT, float iaT, uint32_t keyL)
+{
+#if KAJO_STRICT
+    float ts, th;
+    const bool valid = sphereCandidate(sc, lds, i, O, d, aT, 0.0f, ts, th);
+    const float tsL = __builtin_bit_cast(float, keyL);
+    return valid && !(ts < 0.0f) && (ts < tsL || (ts == tsL && i > si));
+#else
+    const DFloat4 s = lds.sphereHot[i];
+    F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+    float h = dot(d, o);
+    float c = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, __builtin_fmaf(o.z, o.z, -s.w)));
+    float sq = ksqrt(h * h - aT * c);
+    const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
+    const uint32_t kth = klo < khi ? klo : khi;
+    return kth < keyL || (kth == keyL && i > si);
+#endif
+}
+
+// The bin of the light's cube map that u = O - C falls into, and how far from the light's centre the ray reaches.
+KDEV uint32_t shadowBin(const DSceneView& sc, const DSphereCold& lc, int lightK, F3 O, float& reach)
+{
     const F3 u = f3(O.x - lc.cx, O.y - lc.cy, O.z - lc.cz);
     const float ax = __builtin_fabsf(u.x), ay = __builtin_fabsf(u.y), az = __builtin_fabsf(u.z);
     const int m = (ax >= ay && ax >= az) ? 0 : (ay >= az ? 1 : 2);
     const float um = m == 0 ? u.x : (m == 1 ? u.y : u.z);
     const float ua = m == 0 ? u.y : (m == 1 ? u.z : u.x);
     const float ub = m == 0 ? u.z : (m == 1 ? u.x : u.y);
-    // (the hardware reciprocal in both numerics modes: the bin only selects the candidate set, which is conservative by 1e-4 rad)
-    const float im = __builtin_amdgcn_rcpf(__builtin_fabsf(um)); // (u == 0: NaN coordinates fall into cell 0 -- a sphere that close to C is in every bin)
+    // (the hardware reciprocal in both numerics modes: the bin only selects the candidate set, which is conservative by 1e-4 rad;
+    // u == 0: NaN coordinates fall into cell 0 -- a sphere that close to C is in every bin)
+    const float im = __builtin_amdgcn_rcpf(__builtin_fabsf(um));
     const int N = sc.shadow.n;
     const float halfN = 0.5f * (float)N;
     int ia = (int)__builtin_floorf((ua * im + 1.0f) * halfN), ib = (int)__builtin_floorf((ub * im + 1.0f) * halfN);
     ia = min(max(ia, 0), N - 1);
     ib = min(max(ib, 0), N - 1);
     const int face = 2 * m + (um < 0.0f ? 1 : 0);
-    const uint32_t bin = (uint32_t)((((lightK * 6 + face) * N) + ib) * N + ia);
-    const uint32_t k0 = sc.shadow.start[bin], e = sc.shadow.start[bin + 1];
-    const float reach = fmaxf(ksqrt(dot(u, u)), lc.radius) * 1.000001f;
-    // The walk of the bin's list: (key, index) pairs as one 8-byte load each, the NEXT pair requested before the current one is
-    // tested (the lists live in global memory: an L2 round trip per item otherwise, ~8 items per query).
-    const uint2* items = reinterpret_cast<const uint2*>(sc.shadow.items);
-    uint32_t k = k0;
-    uint2 nxt = make_uint2(0x7f800000u, 0u);
-    if (k < e)
-        nxt = items[k];
-    while (k < e) {
-        const uint2 cur = nxt;
-        k++;
-        if (k < e)
-            nxt = items[k];
-        if (__builtin_bit_cast(float, cur.x) > reach) // sorted: nothing further along the list can touch the ray before it ends
-            break;
-        const int i = (int)cur.y;
-#if KAJO_STRICT
-        float ts, th;
-        const bool valid = sphereCandidate(sc, lds, i, O, d, aT, 0.0f, ts, th);
-        if (valid && !(ts < 0.0f) && (ts < tsL || (ts == tsL && i > si)))
-            return false;
-#else
-        const DFloat4 s = lds.sphereHot[i];
-        F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
-        float h = dot(d, o);
-        float c = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, __builtin_fmaf(o.z, o.z, -s.w)));
-        float sq = ksqrt(h * h - aT * c);
-        const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
-        const uint32_t kth = klo < khi ? klo : khi;
-        if (kth < kL || (kth == kL && i > si))
-            return false;
-#endif
-    }
-    return true;
+    reach = fmaxf(ksqrt(dot(u, u)), lc.radius) * 1.000001f;
+    return (uint32_t)((((lightK * 6 + face) * N) + ib) * N + ia);
 }
 
 // ---- surface point of an accepted hit ------------------------------------------------------
@@ -1412,15 +1406,159 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             mode = MODE_HOLD;
         sampleNext = sampleNext && runL;
         KAJO_PROF(5, sampleNext);
+        // the BSDF's colour, exponent and path-weight scale of the vertices whose light / BSDF blocks run in this trip
+        F3 vColor = f3(0.0f, 0.0f, 0.0f);
+        float vExp = 0.0f, vSl = 0.0f;
         if (sampleNext) {
             const DFloat4* vq = reinterpret_cast<const DFloat4*>(lds.material + (vId - 1));
             const DFloat4 v2 = vq[2], v3 = vq[3], v4 = vq[4];
-            const F3 vColor = vKind == 0 ? f3(v3.x, v3.y, v3.z) : f3(v2.x, v2.y, v2.z);
-            const float vExp = v3.w;
-            const float vSl = vKind == 0 ? v4.x : v4.y; // 1/pc * 1/pt * 1/pd, Shader.cpp:160-177
+            vColor = vKind == 0 ? f3(v3.x, v3.y, v3.z) : f3(v2.x, v2.y, v2.z);
+            vExp = v3.w;
+            vSl = vKind == 0 ? v4.x : v4.y; // 1/pc * 1/pt * 1/pd, Shader.cpp:160-177
+        }
+        if (LISTS && runL) {
+            // ---- sampleLights with the shadow query on the spot (Shader.cpp:50-86 as the reference runs it: a vertex's whole loop in
+            // one visit), in ROUNDS the whole wave takes part in: in every round a lane with lights left forms the sample of its next
+            // countable light and does the part of the query that is its own (the light itself, the planes: lightReachedHead); then
+            // the lists of the round's queries are walked by ALL lanes whose ray registers are dead -- a query's owner takes every
+            // (G+1)-th item of its list and G helpers the others, reading the ray from the owner's registers (ds_bpermute) -- because
+            // a wave makes as many item rounds as its longest list has items, and without help a third of the lanes would walk
+            // lists of 5 items on average and 13 at the longest while the rest watch. Which lane tests an item does not change the
+            // test; the owner adds its contribution iff nobody found a blocker: the sums form as before, in light order.
+            volatile uint32_t* helpOwner = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<unsigned char*>(mailbox) + 64 * stealWindow * 16);
+            volatile uint32_t* helpFlag = helpOwner + 64;
+            const uint2* items = reinterpret_cast<const uint2*>(sc.shadow.items);
+            const int nL = sc.nLights;
+            const bool canHelp = sampleNext || pathDone || mode == MODE_DONE; // (their O / d are rewritten before they are read again)
+            int k = sampleNext ? lightK : nL;
+            for (;;) {
+                bool hasQ = false;
+                uint32_t keyL = 0, k0 = 0, e = 0;
+                int si = 0;
+                float reach = 0.0f;
+                if (k < nL) {
+                    // Lights whose sample is discarded whatever it is only draw their random number (see the loop further down)
+                    for (; k < nL; k++) {
+                        if (np + 1 + lds.light[k] == vId) // a light does not sample itself (and draws nothing)
+                            continue;
+                        const DSphereCold& lk = lds.lightCold[k];
+                        const F3 toC = f3(lk.cx - vP.x, lk.cy - vP.y, lk.cz - vP.z);
+                        const bool below = dot(vN, toC) < -(1.001f * lk.radius + 1e-6f * (__builtin_fabsf(toC.x) + __builtin_fabsf(toC.y) + __builtin_fabsf(toC.z)));
+                        if (!(vKind == 2 || below))
+                            break;
+                        rngStep(rng);
+                    }
+                    if (k < nL) {
+                        si = lds.light[k];
+                        const DSphereCold& lc = lds.lightCold[k];
+                        float pl;
+                        d = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
+#if !KAJO_STRICT
+                        pl = lightPdf(lc, vP);
+#endif
+                        float pb;
+                        const F3 fl = bsdfEvaluateWithPdf(vKind, vColor, vExp, vR, vN, d, pb);
+                        const float cosL = kmax0(dot(vN, d));
+                        O = vP + d * kEps;
+                        if (!(pl == 0.0f || pb == 0.0f || cosL == 0.0f)) { // (such a sample adds nothing whatever its shadow ray finds)
+                            const DFloat4 le = lds.lightEmission[k];
+                            pendContrib = ((krcp(pb + pl) * fl) * cosL) * f3(le.x, le.y, le.z);
+                            if (counting)
+                                ctrShadow += 1;
+                            hasQ = lightReachedHead(sc, lds, k, si, O, d, keyL);
+                            if (hasQ) {
+                                const uint32_t bin = shadowBin(sc, lc, k, O, reach);
+                                k0 = sc.shadow.start[bin];
+                                e = sc.shadow.start[bin + 1];
+                            }
+                        }
+                        k++;
+                    }
+                }
+                const unsigned long long qMask = __ballot(hasQ);
+                if (qMask != 0ull) {
+                    // (Giving the helpers to the long lists only -- bins of at least 2 / 4 / 6 / 9 items -- measured the same or worse:
+                    // a bin's length says little about how far along it the ray's reach goes.)
+                    const unsigned long long idleMask = __ballot(!hasQ && canHelp);
+                    const int nQ = __builtin_popcountll(qMask);
+                    int G = __builtin_popcountll(idleMask) / nQ; // helpers per query
+                    G = G > 7 ? 7 : G;
+                    const unsigned long long mine = hasQ ? qMask : idleMask;
+                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+                    if (hasQ) {
+                        helpOwner[rank] = (uint32_t)lane;
+                        helpFlag[lane] = 0u;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const bool helper = !hasQ && canHelp && rank < nQ * G;
+                    int ownerLane = lane, sub = 0;
+                    if (helper) {
+                        const int qr = (int)(((float)rank + 0.5f) * __builtin_amdgcn_rcpf((float)G)); // rank / G (small integers)
+                        sub = 1 + rank - qr * G;
+                        ownerLane = (int)helpOwner[qr];
+                    }
+                    // the query's ray and keys, from its owner's registers (an owner reads its own)
+                    const int addr = ownerLane << 2;
+#define KAJO_FROM_OWNER_F(x) __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, x)))
+#define KAJO_FROM_OWNER_U(x) (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(x))
+                    const F3 qO = f3(KAJO_FROM_OWNER_F(O.x), KAJO_FROM_OWNER_F(O.y), KAJO_FROM_OWNER_F(O.z));
+                    const F3 qd = f3(KAJO_FROM_OWNER_F(d.x), KAJO_FROM_OWNER_F(d.y), KAJO_FROM_OWNER_F(d.z));
+                    const uint32_t qKey = KAJO_FROM_OWNER_U(keyL), qk0 = KAJO_FROM_OWNER_U(k0), qe = KAJO_FROM_OWNER_U(e);
+                    const int qsi = (int)KAJO_FROM_OWNER_U(si);
+                    const float qReach = KAJO_FROM_OWNER_F(reach);
+#undef KAJO_FROM_OWNER_F
+#undef KAJO_FROM_OWNER_U
+                    bool blocked = false;
+                    if (hasQ || helper) {
+                        const float aT = dot(qd, qd);
+#if KAJO_STRICT
+                        const float iaT = 0.0f;
+#else
+                        const float iaT = krcp(aT);
+#endif
+                        // (key, index) pairs, 8 bytes each, the next one requested before the current one is tested; sorted by key
+                        const uint32_t stride = (uint32_t)G + 1u;
+                        uint32_t j = qk0 + (uint32_t)sub;
+                        uint2 nxt = make_uint2(0x7f800000u, 0u);
+                        if (j < qe)
+                            nxt = items[j];
+                        while (j < qe) {
+                            const uint2 cur = nxt;
+                            j += stride;
+                            if (j < qe)
+                                nxt = items[j];
+                            if (__builtin_bit_cast(float, cur.x) > qReach) // nothing further along the list can touch the ray before it ends
+                                break;
+                            if (shadowItemBlocks(sc, lds, (int)cur.y, qsi, qO, qd, aT, iaT, qKey)) {
+                                blocked = true;
+                                break;
+                            }
+                        }
+                        if (helper && blocked)
+                            helpFlag[ownerLane] = 1u;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (hasQ && !blocked && helpFlag[lane] == 0u) { // Shader.cpp:72-80: the closest hit is the light
+#if KAJO_STRICT
+                        vLd = vLd + pendContrib;
+#else
+                        // (the product above stays a rounded value of its own, as in the kernels where it waits a trip for its
+                        // shadow ray: contracted into this sum it would round once -- FAST with and without lists must agree bit for bit)
+                        asm volatile("" : "+v"(pendContrib.x), "+v"(pendContrib.y), "+v"(pendContrib.z));
+                        vE = vE + pendContrib;
+#endif
+                    }
+                }
+                if (__ballot(k < nL) == 0ull)
+                    break;
+            }
+            if (sampleNext)
+                lightK = nL;
+        }
+        if (sampleNext) {
             // ---- sampleLights (Shader.cpp:50-86), one light per trip ------------------------------
             bool shadowRay = false;
-            while (lightK < sc.nLights) {
+            while (!LISTS && lightK < sc.nLights) {
                 // Lights whose sample is discarded whatever it is -- the ideal reflector asks for none (its pdf toward any
                 // given direction is 0, BSDF.cpp:93-96), and a light that lies wholly below the vertex's horizon has
                 // max(0, n.l) = 0 for every point of it -- only draw their random number (Light.cpp:39-41: one draw per
@@ -1492,22 +1630,6 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     continue;
                 }
 #endif
-                if (LISTS) { // Shader.cpp:66-73 on the spot
-                    if (counting)
-                        ctrShadow += 1;
-                    if (lightReached(sc, lds, lightK, si, O, l)) {
-#if KAJO_STRICT
-                        vLd = vLd + pendContrib;
-#else
-                        // (the product above stays a rounded value of its own, as in the kernels where it waits a trip for its
-                        // shadow ray: contracted into this sum it would round once -- FAST with and without lists must agree bit for bit)
-                        asm volatile("" : "+v"(pendContrib.x), "+v"(pendContrib.y), "+v"(pendContrib.z));
-                        vE = vE + pendContrib;
-#endif
-                    }
-                    lightK++;
-                    continue;
-                }
                 mode = MODE_SHADOW;
                 shadowRay = true;
                 break;

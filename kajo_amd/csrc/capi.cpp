@@ -435,12 +435,13 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     }
     if (st.shadowEnabled) {
         // Large scenes with visibility lists: the light loop runs to its end inside one trip (16 lights: ~10 rounds of light
-        // sample + shadow query) and is the expensive block of a trip, with a third of the lanes in it. It runs when 48 lanes
-        // have a vertex waiting or it has been put off three trips in a row; the walk loses lanes to the waiting (lane
-        // efficiency 0.975 -> 0.675) and still the launch gains: FAST 2.35 -> 4.34 G paths/s on the 1000-sphere scene at
-        // 4K x 32 passes, STRICT 1.51 -> 2.54 (profiles/r04_c5_sweep.txt).
-        h->thrL = 48;
-        h->holdTrips = 3;
+        // sample + shadow query) and is the expensive block of a trip, with a third of the lanes in it. It runs when 60 lanes
+        // have a vertex waiting or it has been put off six trips in a row; the walk loses lanes to the waiting (lane
+        // efficiency 0.975 -> 0.64) -- lanes without a ray skip the grid walk, so that costs the walk nothing but the slots -- and
+        // the launch gains: FAST 2.35 -> 4.34 G paths/s on the 1000-sphere scene at 4K x 32 passes with 48 lanes / three trips,
+        // 5.38 -> 5.54 from there to 60 / six once the idle lanes stopped walking stale rays (profiles/r04_c5_notes.txt).
+        h->thrL = 60;
+        h->holdTrips = 6;
     }
     KAJO_TUNE_INT("KAJO_THR_L", 1, 65, h->thrL);
     KAJO_TUNE_INT("KAJO_HOLD_TRIPS", 1, 16, h->holdTrips);

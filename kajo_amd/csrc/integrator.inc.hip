@@ -229,6 +229,8 @@ KDEV bool sphereCandidate(const DSceneView& sc, const LdsScene& lds, int i, F3 O
     float discr = b * b - 4 * a * c;
     // The correctly rounded square root and the two divisions are 38 of this test's 62 instructions; a wave whose rays ALL
     // miss the sphere's line (primary rays of an 8x8 block mostly do) skips them. No lane's result depends on it.
+    // (Lanes without a ray run along with stale registers and vote too; taking their vote away -- one scalar AND per sphere --
+    // measured 1 % slower than the skips it adds are worth.)
     if (__builtin_amdgcn_ballot_w64(!(discr < 0.0f)) == 0ull) {
         ts = th = 0.0f;
         return false;
@@ -374,8 +376,11 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
 #endif
 }
 
+// hasRay: the lane has a ray to trace. Lanes without one (holding a vertex, done) go through the motions of the every-object walk
+// -- it is the same instructions for the whole wave either way -- but must NOT set out on a grid walk with whatever their ray
+// registers hold: a wave walks as long as its longest lane.
 template <bool GRID>
-KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
+KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRay = true)
 {
     float tMax = __builtin_inff(); // Ray.cpp:10-13; minDistance = 0
     int best = 0;
@@ -435,7 +440,8 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d)
     const float iaT = 0.0f;
 #endif
     if (GRID && sc.grid.enabled) {
-        gridWalk(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
+        if (hasRay)
+            gridWalk(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
         return Hit{best, tMax, bestT0};
     }
 #if !KAJO_STRICT
@@ -1267,7 +1273,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
         KAJO_STAMP(0); // camera-ray block
         // ---- one ray per lane through the whole scene ------------------------------------------
-        const Hit hit = trace<!COLD_LDS>(sc, lds, O, d);
+        const Hit hit = trace<!COLD_LDS>(sc, lds, O, d, mode == MODE_EXTEND || mode == MODE_SHADOW);
         KAJO_STAMP(1); // traversal
         if (counting) {
             ctrTraversals += __builtin_popcountll(activeMask);

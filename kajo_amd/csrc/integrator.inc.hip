@@ -1118,7 +1118,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #ifdef KAJO_PROFILE
     // block profile: prof[2k] = wave executions of block k, prof[2k+1] = lanes active in it
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long stampSum[5] = {0, 0, 0, 0, 0};
+    unsigned long long stampSum[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; // [5..8]: inside the light loop of the large-scene kernels
     unsigned long long stampLast = 0;
 #define KAJO_STAMP(k)                                                                                                  \
     do {                                                                                                               \
@@ -1481,6 +1481,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         k++;
                     }
                 }
+                KAJO_STAMP(5); // (light loop of the large-scene kernels: samples + the queries' own part)
                 const unsigned long long qMask = __ballot(hasQ);
                 if (qMask != 0ull) {
                     // (Giving the helpers to the long lists only -- bins of at least 2 / 4 / 6 / 9 items -- measured the same or worse:
@@ -1515,6 +1516,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #undef KAJO_FROM_OWNER_F
 #undef KAJO_FROM_OWNER_U
                     bool blocked = false;
+                    KAJO_STAMP(6); // (helpers found, rays fetched)
                     if (hasQ || helper) {
                         const float aT = dot(qd, qd);
 #if KAJO_STRICT
@@ -1544,6 +1546,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                             helpFlag[ownerLane] = 1u;
                     }
                     __builtin_amdgcn_wave_barrier();
+                    KAJO_STAMP(7); // (lists walked)
                     if (hasQ && !blocked && helpFlag[lane] == 0u) { // Shader.cpp:72-80: the closest hit is the light
 #if KAJO_STRICT
                         vLd = vLd + pendContrib;
@@ -1555,6 +1558,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #endif
                     }
                 }
+                KAJO_STAMP(8); // (contributions added)
                 if (__ballot(k < nL) == 0ull)
                     break;
             }
@@ -1737,7 +1741,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #ifdef KAJO_PROFILE
         for (int k = 0; k < 16; k++)
             atomicAdd(&args.counters[4 + k], prof[k]);
-        for (int k = 0; k < 5; k++)
+        for (int k = 0; k < 9; k++)
             atomicAdd(&args.counters[20 + k], stampSum[k]);
 #endif
     }

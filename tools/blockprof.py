@@ -37,7 +37,10 @@ print('%s %s %dx%d x%d: wave-iterations %.3e, paths %.3e, kernel ms %.2f, trav/p
 for k, n in enumerate(names):
     ex, la = out[2 * k], out[2 * k + 1]
     print('%-18s executed in %5.1f%% of iterations, %4.1f lanes active when executed (%.0f%%)' % (n, 100 * ex / iters, la / max(ex, 1), 100 * la / max(ex, 1) / 64))
-st = [out[16 + k] for k in range(5)]
+st = [out[16 + k] for k in range(9)]
+if not DEFERRED and any(st[5:]):  # the large-scene kernels stamp inside their light loop: stamp 3 is then what follows the loop (BSDF sampling)
+    stamps = stamps[:3] + ['BSDF sampling (after the light loop)', stamps[4], 'light loop: samples + own part of the queries', 'light loop: helpers found, rays fetched',
+                           'light loop: lists walked', 'light loop: contributions added']
 tot = sum(st)
 for n, v in zip(stamps, st):
-    print('%-28s %5.1f%% of wave time, %.0f cycles per iteration' % (n, 100 * v / tot, v / iters))
+    print('%-46s %5.1f%% of wave time, %.0f cycles per iteration' % (n, 100 * v / tot, v / iters))

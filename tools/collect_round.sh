@@ -1,12 +1,13 @@
 #!/bin/bash
 # Copy what tools/profile_round.sh left under gpurun_out/<tag>prof/ into profiles/ (the files the docs cite).
-R=${1:-r03}; P=gpurun_out/${R}prof
+R=${1:-r04}; P=gpurun_out/${R}prof
 [ -f $P/bench_final.json ] && cp $P/bench_final.json profiles/${R}_bench.json || cp $P/bench.json profiles/${R}_bench.json
 grep -v amdgpu.ids $P/configs.txt > profiles/${R}_configs.txt
 cp $P/pmc_fast.txt profiles/${R}_pmc_fast.txt; cp $P/pmc_strict.txt profiles/${R}_pmc_strict.txt; cp $P/counters.json profiles/${R}_counters.json
 [ -f $P/size_sweep.txt ] && grep -v amdgpu.ids $P/size_sweep.txt > profiles/${R}_size_sweep.txt
 for k in fast strict; do f=$(ls -t $P/stats_$k/*/*kernel_stats.csv | head -1); cp $f profiles/${R}_bench_kernel_stats_$k.csv; done
-for k in fast strict fast_stress; do grep -v amdgpu.ids $P/blockprof_$k.txt > profiles/${R}_blockprof_$k.txt; done
+for k in fast strict fast_stress strict_stress; do [ -f $P/blockprof_$k.txt ] && grep -v amdgpu.ids $P/blockprof_$k.txt > profiles/${R}_blockprof_$k.txt; done
+[ -f $P/rank_share.txt ] && grep -v amdgpu.ids $P/rank_share.txt > profiles/${R}_rank_share_table.txt
 python3 - <<PY
 import json
 d=json.loads(open('profiles/${R}_bench.json').read().strip().splitlines()[-1])

@@ -33,4 +33,11 @@ echo "configs done"
 python3 tools/blockprof.py fast spheres > $OUT/blockprof_fast.txt 2>&1
 python3 tools/blockprof.py strict spheres > $OUT/blockprof_strict.txt 2>&1
 python3 tools/blockprof.py fast stress 1920 1080 8 > $OUT/blockprof_fast_stress.txt 2>&1
-echo all done
+echo profiles done
+# the bench line again, now that <tag>_counters.json of these kernels exists (roofline.traffic / executed_flops are read from it)
+cp $OUT/counters.json profiles/${R}_counters.json
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_final.json 2> $OUT/bench_final.err
+python3 tools/rank_share.py > $OUT/rank_share.txt 2>&1
+python3 tools/size_sweep.py > $OUT/size_sweep.txt 2>&1
+python3 tools/blockprof.py strict stress 1920 1080 4 > $OUT/blockprof_strict_stress.txt 2>&1
+echo final bench done

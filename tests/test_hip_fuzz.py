@@ -65,3 +65,49 @@ def test_fast_close_to_oracle_on_random_parameters(scenes):
             # same streams: most pixels agree to rounding; a pixel may take another path at an ill-conditioned hit
             assert np.median(d) <= 2e-5 * max(1.0, float(np.median(np.abs(want[both])))), (c, float(np.median(d)))
             assert np.mean(d > 1e-2 * np.maximum(1.0, np.abs(want[both]))) <= 0.03, c
+
+
+def test_strict_equals_oracle_on_random_large_scenes(scenes):
+    """The large-scene kernels on seeded draws: 50-400 spheres (jittered-grid scenes and adversarial ones: overlapping, nested,
+    clipped lights), 1-12 lights, ragged frames, tile owners, passes split over launches, depth limits -- visibility lists,
+    light loop in rounds with helper lanes, holding: STRICT must equal the oracle's every-object walk bit for bit, whichever
+    way the shadow rays go (lists / grid), and FAST must give the same buffer either way."""
+    from oraclelib import OracleLib, available
+    from kajo_amd import capi
+    from kajo_amd.scene import stress_scene
+    from test_shadow_lists_cpu import adversarial_scene
+    if not available("oracle"):
+        pytest.skip("oracle not built")
+    lib = OracleLib("oracle")
+    rng = np.random.default_rng(424242)
+    base = scenes["spheres_a169"]
+    for draw in range(10):
+        if draw % 3 == 2:
+            sc = adversarial_scene(base, int(rng.integers(10, 1000)), n=int(rng.integers(60, 160)), n_lights=int(rng.integers(1, 8)))
+        else:
+            sc = stress_scene(base, int(rng.integers(50, 400)), int(rng.integers(1, 13)), seed=int(rng.integers(1, 10000)))
+        W, H = int(rng.choice([33, 64, 97, 120])), int(rng.choice([17, 40, 54]))
+        S, passes, depth = int(rng.choice([4, 9, 16])), int(rng.integers(1, 4)), int(rng.integers(1, 9))
+        ppl, seed = int(rng.choice([0, 1, 2])), int(rng.integers(1, 2 ** 40))
+        owners = int(rng.choice([1, 1, 2, 3]))
+        want = lib.create(sc, 1).render(W, H, S=S, passes=passes, seed=seed, depth_limit=depth, threads=8)
+        for flags in (0, capi.KAJO_FLAG_NO_SHADOW_LISTS):
+            # the owners' tiles, composed on the host (kajo_amd.tiles): any partition gives the one-owner frame
+            from kajo_amd.tiles import TileLayout
+            import torch
+            from bench import DevicePtr
+            bufs = []
+            for o in range(owners):
+                with HipRenderer(sc, W, H, spp=S, depth_limit=depth, seed=seed, strict=True, passes_per_launch=ppl, flags=flags,
+                                 tile_index=o, tile_count=owners) as r:
+                    r.render(passes).wait()
+                    ptr, nbytes = r.tile_buffer()
+                    bufs.append(torch.as_tensor(DevicePtr(ptr, nbytes // 4), device="cuda").cpu().numpy().reshape(-1, 4).copy())
+            got = TileLayout(W, H, owners).compose(np.stack(bufs))
+            same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            assert same[..., :3].all(), (draw, sc.name, W, H, S, passes, depth, ppl, owners, flags, int((~same[..., :3]).sum()))
+        fast = []
+        for flags in (0, capi.KAJO_FLAG_NO_SHADOW_LISTS):
+            with HipRenderer(sc, W, H, spp=S, depth_limit=depth, seed=seed, passes_per_launch=ppl, flags=flags) as r:
+                fast.append(r.render(passes).radiance())
+        assert ((fast[0].view(np.uint32) == fast[1].view(np.uint32)) | (np.isnan(fast[0]) & np.isnan(fast[1]))).all(), (draw, sc.name)

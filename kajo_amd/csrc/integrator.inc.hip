@@ -1054,12 +1054,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // (the handle zeroes the buffer when it is created or reset)
     F3 total = f3(0.0f, 0.0f, 0.0f);
     float totalW = 0.0f;
-    if (!KAT && inImage) {
+    if (!KAT && !LISTS && inImage) {
         const float4 t = reinterpret_cast<const float4*>(args.tiles)[slot];
         total = f3(t.x, t.y, t.z);
         totalW = t.w;
     }
     bool katStarted = false;
+    // (LISTS kernels -- 128 VGPRs and spilling -- do not carry the pixel's total through the loop: a pass end adds its term to the
+    // tile buffer in place, one coalesced 16-byte read and write per 25 paths; the same additions in the same order.)
 
     // ---- per-lane path state ----------------------------------------------------------------
     int mode = inImage ? MODE_NEW : MODE_DONE;
@@ -1194,7 +1196,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     mailbox[stolenFrom * stealWindow + (pass - stealBase)] = DFloat4{term.x, term.y, term.z, 0.0f};
                     stolenFrom = -1;
                 } else {
-                    total = total + term;
+                    if (LISTS) {
+                        float4* acc = reinterpret_cast<float4*>(args.tiles) + slot;
+                        const float4 t4 = *acc;
+                        *acc = make_float4(t4.x + term.x, t4.y + term.y, t4.z + term.z, t4.w);
+                    } else {
+                        total = total + term;
+                    }
                     ownPass++;
                 }
                 radiance = f3(0.0f, 0.0f, 0.0f);
@@ -1504,21 +1512,29 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         sub = 1 + rank - qr * G;
                         ownerLane = (int)helpOwner[qr];
                     }
-                    // the query's ray and keys, from its owner's registers (an owner reads its own)
+                    // The query's ray and keys from its owner's registers, IN PLACE: an owner reads its own lane, and so does every lane
+                    // that is neither owner nor helper -- their registers keep their values; a helper's are dead (canHelp). No second
+                    // set of eleven registers in a kernel that has none to spare.
                     const int addr = ownerLane << 2;
-#define KAJO_FROM_OWNER_F(x) __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, x)))
-#define KAJO_FROM_OWNER_U(x) (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(x))
-                    const F3 qO = f3(KAJO_FROM_OWNER_F(O.x), KAJO_FROM_OWNER_F(O.y), KAJO_FROM_OWNER_F(O.z));
-                    const F3 qd = f3(KAJO_FROM_OWNER_F(d.x), KAJO_FROM_OWNER_F(d.y), KAJO_FROM_OWNER_F(d.z));
-                    const uint32_t qKey = KAJO_FROM_OWNER_U(keyL), qk0 = KAJO_FROM_OWNER_U(k0), qe = KAJO_FROM_OWNER_U(e);
-                    const int qsi = (int)KAJO_FROM_OWNER_U(si);
-                    const float qReach = KAJO_FROM_OWNER_F(reach);
+#define KAJO_FROM_OWNER_F(x) x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, x)))
+#define KAJO_FROM_OWNER_U(x) x = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(x))
+                    KAJO_FROM_OWNER_F(O.x);
+                    KAJO_FROM_OWNER_F(O.y);
+                    KAJO_FROM_OWNER_F(O.z);
+                    KAJO_FROM_OWNER_F(d.x);
+                    KAJO_FROM_OWNER_F(d.y);
+                    KAJO_FROM_OWNER_F(d.z);
+                    KAJO_FROM_OWNER_U(keyL);
+                    KAJO_FROM_OWNER_U(k0);
+                    KAJO_FROM_OWNER_U(e);
+                    si = (int)__builtin_amdgcn_ds_bpermute(addr, si);
+                    KAJO_FROM_OWNER_F(reach);
 #undef KAJO_FROM_OWNER_F
 #undef KAJO_FROM_OWNER_U
                     bool blocked = false;
                     KAJO_STAMP(6); // (helpers found, rays fetched)
                     if (hasQ || helper) {
-                        const float aT = dot(qd, qd);
+                        const float aT = dot(d, d);
 #if KAJO_STRICT
                         const float iaT = 0.0f;
 #else
@@ -1526,18 +1542,18 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #endif
                         // (key, index) pairs, 8 bytes each, the next one requested before the current one is tested; sorted by key
                         const uint32_t stride = (uint32_t)G + 1u;
-                        uint32_t j = qk0 + (uint32_t)sub;
+                        uint32_t j = k0 + (uint32_t)sub;
                         uint2 nxt = make_uint2(0x7f800000u, 0u);
-                        if (j < qe)
+                        if (j < e)
                             nxt = items[j];
-                        while (j < qe) {
+                        while (j < e) {
                             const uint2 cur = nxt;
                             j += stride;
-                            if (j < qe)
+                            if (j < e)
                                 nxt = items[j];
-                            if (__builtin_bit_cast(float, cur.x) > qReach) // nothing further along the list can touch the ray before it ends
+                            if (__builtin_bit_cast(float, cur.x) > reach) // nothing further along the list can touch the ray before it ends
                                 break;
-                            if (shadowItemBlocks(sc, lds, (int)cur.y, qsi, qO, qd, aT, iaT, qKey)) {
+                            if (shadowItemBlocks(sc, lds, (int)cur.y, si, O, d, aT, iaT, keyL)) {
                                 blocked = true;
                                 break;
                             }
@@ -1725,6 +1741,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
         }
     } else if (!KAT && inImage) {
+        if (LISTS) { // (the own passes' terms are in the buffer already)
+            const float4 t4 = reinterpret_cast<const float4*>(args.tiles)[slot];
+            total = f3(t4.x, t4.y, t4.z);
+            totalW = t4.w;
+        }
         // passes of this pixel that other lanes rendered, in pass order
         for (int p = myEnd; p < lastPass; p++) {
             const DFloat4 t = mailbox[lane * stealWindow + (p - stealBase)];

@@ -419,7 +419,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     // overrides from the environment (tuning.h); libkajo_hip.so contains no getenv.
     const bool big = st.gridEnabled || hotBytes + coldBytes > 40 * 1024;
     h->stealWindow = 4;
-    h->helpBytes = (st.shadowEnabled || (!big && !h->strict())) ? 512 : 0; // (the FAST small-scene loop answers shadow rays cooperatively too)
+    h->helpBytes = st.shadowEnabled ? 512 : 0;
     KAJO_TUNE_INT("KAJO_STEAL_WINDOW", 1, 16, h->stealWindow);
     KAJO_TUNE_INT("KAJO_LDS_EXTRA", 0, 64 * 1024, h->ldsExtra);
     h->ldsExtra &= ~15;

@@ -878,9 +878,6 @@ enum : int
 #ifndef KAJO_INLINE_SHADOW
 #define KAJO_INLINE_SHADOW 0
 #endif
-#ifndef KAJO_COOP_SHADOW
-#define KAJO_COOP_SHADOW 0
-#endif
 
 namespace
 {
@@ -1008,8 +1005,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
 // light's visibility lists (lightReached) instead of costing the lane a trip of its own through the grid: the light loop of a
 // vertex runs to its end in ONE trip, as Shader::sampleLights does (Shader.cpp:50-86), and every trip's walk carries camera and
 // extension rays only. Same draws, same tests, same sums in the same order: the buffer does not change by a bit.
-// COOP (small scenes, FAST build): shadow rays answered inside the light loop by the wave's idle lanes (see the block further down).
-template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool LISTS = false, bool COOP = false>
+template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool LISTS = false>
 KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 {
     const DSceneView& sc = args.scene;
@@ -1386,7 +1382,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     }
                 }
             }
-        } else if (!LISTS && !COOP && mode == MODE_SHADOW) {
+        } else if (!LISTS && mode == MODE_SHADOW) {
             // Shader.cpp:72-73: the sample counts iff the closest hit of the shadow ray IS the light
             if (hit.id == np + 1 + lds.light[lightK]) {
 #if KAJO_STRICT
@@ -1585,131 +1581,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             if (sampleNext)
                 lightK = nL;
         }
-#if KAJO_COOP_SHADOW && !KAJO_STRICT
-        // Small scenes, FAST build: the shadow ray of a light sample is answered right here, by the lanes of the wave that have nothing
-        // else to do -- the light loop runs in rounds as in the large-scene kernels above, but a query's "list" is simply every other
-        // object of the scene, dealt to its owner and G idle lanes (ds_bpermute hands them the ray), each testing every (G+1)-th plane
-        // and sphere with the closest-hit walk's own arithmetic. A shadow ray then costs its lane no trip of its own (1.69 -> 1.53
-        // walks per path in the trip loop) and the vertex's BSDF sample follows in the same visit. The decision is the walk's
-        // (trace(), rigid planes and translated spheres: t compared for planes, a t for spheres, a later object winning ties) in
-        // its order-independent form: a plane blocks iff bits(t a) < the light's key; a sphere before the light iff its key is
-        // smaller, one after it iff smaller or equal. Scenes with other plane / sphere records keep the shadow trips.
-        constexpr bool coopSmall = COOP; // (the host launches this kernel for scenes of rigid planes and translated spheres only)
-        if (coopSmall && runL) {
-            volatile uint32_t* helpOwner = reinterpret_cast<volatile uint32_t*>(reinterpret_cast<unsigned char*>(mailbox) + 64 * stealWindow * 16);
-            volatile uint32_t* helpFlag = helpOwner + 64;
-            const int nL = sc.nLights, ns = sc.nSpheres;
-            const bool canHelp = sampleNext || pathDone || mode == MODE_DONE; // (their O / d are rewritten before they are read again)
-            int k = sampleNext ? 0 : nL; // (a vertex's light loop always starts and ends inside one visit here)
-            for (;;) {
-                bool hasQ = false;
-                uint32_t keyL = 0;
-                int si = 0;
-                while (k < nL && np + 1 + lds.light[k] == vId) // a light does not sample itself (and draws nothing)
-                    k++;
-                if (k < nL) {
-                    si = lds.light[k];
-                    const DSphereCold& lc = lds.lightCold[k];
-                    float pl;
-                    d = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
-                    pl = lightPdf(lc, vP);
-                    float pb;
-                    const F3 fl = bsdfEvaluateWithPdf(vKind, vColor, vExp, vR, vN, d, pb);
-                    const float cosL = kmax0(dot(vN, d));
-                    O = vP + d * kEps;
-                    if (!(pl == 0.0f || pb == 0.0f || cosL == 0.0f)) { // (such a sample adds nothing whatever its shadow ray finds)
-                        const DFloat4 le = lds.lightEmission[k];
-                        pendContrib = ((krcp(pb + pl) * fl) * cosL) * f3(le.x, le.y, le.z);
-                        if (counting)
-                            ctrShadow += 1;
-                        // the light itself: its key in the sphere walk's a t space
-                        const DFloat4 sL = lds.sphereHot[si];
-                        const F3 o = f3(O.x + sL.x, O.y + sL.y, O.z + sL.z);
-                        const float aT = dot(d, d), h = dot(d, o);
-                        const float c = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, __builtin_fmaf(o.z, o.z, -sL.w)));
-                        const float sq = ksqrt(h * h - aT * c);
-                        const uint32_t klo = __builtin_bit_cast(uint32_t, -h - sq), khi = __builtin_bit_cast(uint32_t, sq - h);
-                        keyL = klo < khi ? klo : khi;
-                        hasQ = keyL <= 0x7f800000u;
-                    }
-                    k++;
-                }
-                const unsigned long long qMask = __ballot(hasQ);
-                if (qMask != 0ull) {
-                    const unsigned long long idleMask = __ballot(!hasQ && canHelp);
-                    const int nQ = __builtin_popcountll(qMask);
-                    int G = __builtin_popcountll(idleMask) / nQ; // helpers per query
-                    G = G > 7 ? 7 : G;
-                    const unsigned long long mine = hasQ ? qMask : idleMask;
-                    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
-                    if (hasQ) {
-                        helpOwner[rank] = (uint32_t)lane;
-                        helpFlag[lane] = 0u;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const bool helper = !hasQ && canHelp && rank < nQ * G;
-                    int ownerLane = lane, sub = 0;
-                    if (helper) {
-                        const int qr = (int)(((float)rank + 0.5f) * __builtin_amdgcn_rcpf((float)G)); // rank / G (small integers)
-                        sub = 1 + rank - qr * G;
-                        ownerLane = (int)helpOwner[qr];
-                    }
-                    // the ray, the light's key and index from the owner's registers, in place (see the large-scene loop)
-                    const int addr = ownerLane << 2;
-#define KAJO_FROM_OWNER_F(x) x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, x)))
-                    KAJO_FROM_OWNER_F(O.x);
-                    KAJO_FROM_OWNER_F(O.y);
-                    KAJO_FROM_OWNER_F(O.z);
-                    KAJO_FROM_OWNER_F(d.x);
-                    KAJO_FROM_OWNER_F(d.y);
-                    KAJO_FROM_OWNER_F(d.z);
-#undef KAJO_FROM_OWNER_F
-                    keyL = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)keyL);
-                    si = __builtin_amdgcn_ds_bpermute(addr, si);
-                    bool blocked = false;
-                    if (hasQ || helper) {
-                        const float aT = dot(d, d);
-                        const int stride = G + 1;
-                        for (int p = sub; p < np; p += stride) { // trace()'s rigid-plane test; the plane's t in the spheres' a t space
-                            const DFloat4 r = lds.planeRow[p];
-                            const float denom = r.x * d.x + r.y * d.y + r.z * d.z;
-                            const float oy = __builtin_fmaf(r.x, O.x, __builtin_fmaf(r.y, O.y, __builtin_fmaf(r.z, O.z, r.w)));
-                            const float t = __builtin_fmaf(-oy, krcp(denom), 0.0f);
-                            const bool valid = !(__builtin_fabsf(denom) < kFltEpsilon) && __builtin_bit_cast(uint32_t, t) <= 0x7f800000u;
-                            blocked = blocked || (valid && __builtin_bit_cast(uint32_t, t * aT) < keyL);
-                        }
-                        for (int i = sub; i < ns; i += stride) { // trace()'s translated-sphere test
-                            const DFloat4 sp = lds.sphereHot[i];
-                            const F3 o = f3(O.x + sp.x, O.y + sp.y, O.z + sp.z);
-                            const float h = dot(d, o);
-                            const float c = __builtin_fmaf(o.x, o.x, __builtin_fmaf(o.y, o.y, __builtin_fmaf(o.z, o.z, -sp.w)));
-                            const float sq = ksqrt(h * h - aT * c);
-                            const uint32_t klo = __builtin_bit_cast(uint32_t, -h - sq), khi = __builtin_bit_cast(uint32_t, sq - h);
-                            const uint32_t kth = klo < khi ? klo : khi;
-                            blocked = blocked || (i < si ? kth < keyL : (i > si && kth <= keyL));
-                        }
-                        if (helper && blocked)
-                            helpFlag[ownerLane] = 1u;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    if (hasQ && !blocked && helpFlag[lane] == 0u) { // Shader.cpp:72-80: the closest hit is the light
-                        asm volatile("" : "+v"(pendContrib.x), "+v"(pendContrib.y), "+v"(pendContrib.z)); // (a rounded value of its own, as when it waited a trip)
-                        vE = vE + pendContrib;
-                    }
-                }
-                if (__ballot(k < nL) == 0ull)
-                    break;
-            }
-            if (sampleNext)
-                lightK = nL;
-        }
-#else
-        constexpr bool coopSmall = false;
-#endif
         if (sampleNext) {
             // ---- sampleLights (Shader.cpp:50-86), one light per trip ------------------------------
             bool shadowRay = false;
-            while (!LISTS && !coopSmall && lightK < sc.nLights) {
+            while (!LISTS && lightK < sc.nLights) {
                 // Lights whose sample is discarded whatever it is -- the ideal reflector asks for none (its pdf toward any
                 // given direction is 0, BSDF.cpp:93-96), and a light that lies wholly below the vertex's horizon has
                 // max(0, n.l) = 0 for every point of it -- only draw their random number (Light.cpp:39-41: one draw per
@@ -1928,15 +1803,6 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBody<false, false>(args, ldsRaw);
 }
-
-#if KAJO_COOP_SHADOW && !KAJO_STRICT
-// small scenes of rigid planes and translated spheres, FAST: shadow rays answered cooperatively inside the light loop (renderBody COOP)
-extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_COOP(const RenderArgs args)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    renderBody<true, false, false, false, true>(args, ldsRaw);
-}
-#endif
 
 // large scenes with per-light visibility lists: shadow queries answered inside the light loop (renderBody LISTS)
 extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KERNEL_NAME_BIGLIST(const RenderArgs args)

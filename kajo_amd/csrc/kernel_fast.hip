@@ -6,7 +6,6 @@
 #define KAJO_KERNEL_NAME kajo_render_fast
 #define KAJO_KERNEL_NAME_BIG kajo_render_fast_big
 #define KAJO_KERNEL_NAME_BIGLIST kajo_render_fast_biglist
-#define KAJO_KERNEL_NAME_COOP kajo_render_fast_coop
 #define KAJO_KERNEL_NAME_SPLIT kajo_render_fast_split
 #define KAJO_KAT_SHADE_NAME kajo_kat_shade_fast
 #define KAJO_KAT_TRACE_NAME kajo_kat_trace_fast

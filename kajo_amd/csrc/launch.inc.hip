@@ -7,11 +7,6 @@
 extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _launch)(const RenderArgs* args, int coldInLds, unsigned grid, unsigned block,
                                                 size_t ldsBytes, void* stream)
 {
-#if KAJO_COOP_SHADOW && !KAJO_STRICT
-    if (coldInLds && args->scene.planesRigid && args->scene.allTranslated && args->scene.nLights > 0) // (coldInLds == 2: not this launch)
-        hipLaunchKernelGGL(KAJO_KERNEL_NAME_COOP, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
-    else
-#endif
     if (coldInLds)
         hipLaunchKernelGGL(KAJO_KERNEL_NAME, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
     else if (args->scene.shadow.enabled)

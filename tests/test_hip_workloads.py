@@ -95,7 +95,7 @@ def check_against_reference_fixture(golden, key, scene, crops, passes, strict, f
     return rows
 
 
-def check_workload(scene, W, H, S, passes, depth, limit=10, fast_px_budget=0.004, ppl=0, slack=1.5, golden=None, fixture=None, min_identical=0.3):
+def check_workload(scene, W, H, S, passes, depth, limit=10, fast_px_budget=0.004, ppl=0, slack=1.5, golden=None, fixture=None, min_identical=0.3, fast_north_star=None):
     crops = crops_for(scene, W, H, limit)
     assert len(crops) >= 8
     O = OracleLib("oracle")
@@ -161,6 +161,8 @@ def check_workload(scene, W, H, S, passes, depth, limit=10, fast_px_budget=0.004
     record({"key": "%s %dx%d FAST vs oracle(libm) at %d passes" % (scene.name, W, H, passes), "frame": "%dx%d" % (W, H), "passes": passes,
             "fast_rmse_over_crops": float(cl_all), "meets_1e-4": bool(cl_all < 1e-4),
             "crops": [{"crop": r[0], "fast_vs_oracle_libm_rmse": r[3], "px_off_by_more_than_1e-3": r[4], "reference_fastmath_vs_O2_rmse": r[6][2]} for r in report]})
+    if fast_north_star is not None:  # BASELINE.json's per-pixel RMSE bound, where the pass count lets FAST meet it (profiles/r04_parity.json)
+        assert cl_all < fast_north_star, (scene.name, passes, float(cl_all))
     if refs:  # the reference libraries travelled: STRICT against the reference's -O2 build rendered here, crop by crop
         for name, x, y, w, h in crops:
             g, ref = strict[y:y + h, x:x + w, :3], floors[("ref_strict", name)] * passes
@@ -202,7 +204,8 @@ def test_configs1_spheres_1080p_16_passes(scenes, golden):
 def test_configs2_spheres_4k_64_passes(scenes, golden):
     """The multi-GPU frame at its own size and pass count, all 64 passes in one launch as bench.py renders it."""
     sc = scenes["spheres_a169"]
-    check_workload(sc, 3840, 2160, 32, 64, 8, limit=8, ppl=64, golden=golden, fixture="c3_4k")
+    # at configs[2]'s 64 passes FAST meets the north-star bound itself: 4.1e-5 over the eight crops (4.7e-5 on a whole small frame)
+    check_workload(sc, 3840, 2160, 32, 64, 8, limit=8, ppl=64, golden=golden, fixture="c3_4k", fast_north_star=1e-4)
     # and as rank 0 of two tile owners would render it: the owned half of the tiles, bit for bit the one-owner frame's
     crops = crops_for(sc, 3840, 2160, 8)
     with HipRenderer(sc, 3840, 2160, spp=32, depth_limit=8, seed=SEED, passes_per_launch=64) as r:
@@ -278,7 +281,8 @@ def check_full_pass_count(golden, fixture, scene, W, H, S, passes, depth, ncrops
 def test_configs3_caustics_at_all_128_passes(scenes, golden):
     """configs[3] at its own 4096 spp = 128 passes x S = 32 (Renderer.cpp:44-72 runs the pass loop that long): three crops."""
     # (128 passes of 25 paths: 3200 last-place differences to collect per pixel -- a quarter of the pixels still are the reference's bit for bit)
-    check_full_pass_count(golden, "c4_1080p_128", scenes["caustics_a169"], 1920, 1080, 32, 128, 8, 3, 16, min_identical=0.15)
+    # (FAST over these crops at 128 passes: 4.2e-5)
+    check_full_pass_count(golden, "c4_1080p_128", scenes["caustics_a169"], 1920, 1080, 32, 128, 8, 3, 16, min_identical=0.15, fast_north_star=1e-4)
 
 
 def test_configs4_stress_at_all_32_passes(scenes, golden):

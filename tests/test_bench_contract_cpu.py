@@ -1,0 +1,45 @@
+"""The bench line's contract, checked on the line committed from this round's GPU run (profiles/r04_bench.json): the fields the
+driver reads, the roofline and cpu_baseline objects, and the arithmetic that ties them together (no GPU needed: what bench.py
+prints is data once it is committed)."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def load():
+    txt = open(os.path.join(ROOT, "profiles", "r04_bench.json")).read()
+    return json.loads([l for l in txt.splitlines() if l.startswith("{")][-1])
+
+
+def test_fields_and_arithmetic():
+    d = load()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "Msamples/s" and d["unit"] == "Msamples/s" and d["n_gpus"] == 1 and d["higher_is_better"] is True
+    assert d["dtype"] == "f32" and d["data"] == "synthetic" and d["vs_baseline"] is None  # BASELINE.md has no published number
+    assert "1920x1080" in d["config"]["workload"] and "512 spp" in d["config"]["workload"] and "model" not in d["config"]
+    # value = paths of a step / time of a step
+    assert abs(d["value"] - d["config"]["paths_per_step"] / (d["ms_per_step"] * 1e-3) / 1e6) / d["value"] < 1e-6
+    r = d["roofline"]
+    assert r["bound"] == "valu" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    # achieved = algorithmic FLOP per path x paths per launch / the kernel's average duration
+    achieved = r["flops_per_path"] * d["config"]["paths_per_step"] / r["launches_per_step"] / (r["kernel_ms_per_launch"] * 1e-3) / 1e12
+    assert abs(achieved - r["achieved"]) / r["achieved"] < 1e-6
+    assert r["kernel_ms_per_launch"] <= d["ms_per_step"]
+    # HBM traffic from the PMC counters: present (collected on these very kernels) and close to the algorithmic 32 B per pixel
+    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["hbm"]["algorithmic_bytes_per_launch"] < 1.1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "reference" and c["unit"] == "Msamples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["speedup_vs_cpu_baseline"] - d["value"] / c["value"]) < 1e-6 * d["speedup_vs_cpu_baseline"]
+
+
+def test_plugin_path_and_north_star_mode():
+    d = load()
+    s = d["scheduler_run"]  # hip::Scheduler::run() through kajo_render: within a few per cent of the C-ABI step, host read-back included
+    assert "read-back" in s["includes"] and 0.9 < s["value"] / d["value"] < 1.02
+    n = d["north_star_mode"]  # >= 100x the CPU backend AND per-pixel RMSE < 1e-4 at once
+    assert n["numerics"] == "strict" and n["rmse"] < 1e-4 and n["speedup_vs_cpu_baseline"] >= 100 and n["bit_identical_px"] == n["px"]
+    assert d["parity"]["rmse_clamped01"] < 1e-3  # FAST: inside SURVEY section 8c's tolerance
+    assert d["config"]["tuning_env"] == {} and d["config"]["library"].endswith("libkajo_hip.so")

@@ -440,6 +440,14 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
     const float iaT = 0.0f;
 #endif
     if (GRID && sc.grid.enabled) {
+#if KAJO_STRICT
+        // A ray that is not a number (a light sample whose square root went negative, Light.cpp:43-46; the Phong frame of a
+        // reflection along z, BSDF.cpp:52-54): in the reference's walk every comparison with NaN is false, so every object is
+        // "accepted" and the LAST one wins (Raytracer.cpp:115,131-132). The every-object walk below does that by itself; the grid
+        // walk has to be told.
+        if (!(aT == aT) && ns > 0)
+            return Hit{np + ns, aT, aT};
+#endif
         if (hasRay)
             gridWalk(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
         return Hit{best, tMax, bestT0};
@@ -498,6 +506,10 @@ KDEV bool lightReachedHead(const DSceneView& sc, const LdsScene& lds, int lightK
     const int np = sc.nPlanes;
     const float aT = dot(d, d);
 #if KAJO_STRICT
+    if (!(aT == aT)) { // a ray that is not a number: the reference's poisoned walk ends on the LAST object (see trace()); no test below blocks
+        keyL = 0x7fc00000u;
+        return si == sc.nSpheres - 1;
+    }
     float tsL, thL;
     if (!sphereCandidate(sc, lds, si, O, d, aT, 0.0f, tsL, thL) || tsL < 0.0f)
         return false;
@@ -877,6 +889,11 @@ enum : int
 #endif
 #ifndef KAJO_INLINE_SHADOW
 #define KAJO_INLINE_SHADOW 0
+#endif
+#if KAJO_STRICT
+#define KAJO_IS_A_NUMBER(x) ((x) == (x))
+#else
+#define KAJO_IS_A_NUMBER(x) true
 #endif
 
 namespace
@@ -1474,7 +1491,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         const F3 fl = bsdfEvaluateWithPdf(vKind, vColor, vExp, vR, vN, d, pb);
                         const float cosL = kmax0(dot(vN, d));
                         O = vP + d * kEps;
-                        if (!(pl == 0.0f || pb == 0.0f || cosL == 0.0f)) { // (such a sample adds nothing whatever its shadow ray finds)
+                        if (!(pl == 0.0f || pb == 0.0f || (cosL == 0.0f && KAJO_IS_A_NUMBER(pb)))) { // (such a sample adds nothing whatever its shadow ray finds; see the loop further down)
                             const DFloat4 le = lds.lightEmission[k];
                             pendContrib = ((krcp(pb + pl) * fl) * cosL) * f3(le.x, le.y, le.z);
                             if (counting)
@@ -1627,7 +1644,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // finds (the sum stays as it is: x + (+-0) == x), so that walk is skipped as well.
                 const float cosL = kmax0(dot(vN, l));
                 O = vP + l * kEps;
-                if (pl == 0.0f || pb == 0.0f || cosL == 0.0f) {
+                // (... unless the sample is NOT A NUMBER: r^2 - x^2 - y^2 of Light.cpp:43-46 rounds below zero once in ~1e8 samples, its
+                // square root makes the direction NaN, and the reference then adds f * max(0, NaN) * Le / (NaN + pl) = NaN when the
+                // poisoned walk -- every comparison with NaN is false, so every object is "accepted" and the last one wins,
+                // Raytracer.cpp:115 -- ends on the light. max(0, NaN) is 0 here as there, so the cosine alone would have skipped the
+                // sample: two pixels of the 1080p x 16-pass frame, finite here and NaN in the reference, until round 4 compared whole frames.)
+                // FAST, whose walk rejects NaN distances by their bit patterns, keeps skipping on the cosine (its loop has no scalar register
+                // for the extra test, and its NaN pixels are counted, not matched).
+                if (pl == 0.0f || pb == 0.0f || (cosL == 0.0f && KAJO_IS_A_NUMBER(pb))) {
                     lightK++;
                     continue;
                 }

@@ -188,3 +188,27 @@ def test_trace_origin_exactly_on_a_surface(scenes):
     assert zero.sum() >= 6
     assert np.array_equal(fast["idx"][zero], want["idx"][zero]), (fast["idx"], want["idx"], robust)
     assert (fast["t"][zero] == 0).all()
+
+
+def test_light_sample_that_is_not_a_number(scenes):
+    """Light.cpp:43-46: z = sqrt(r^2 - x^2 - y^2) * sin(..) -- the difference rounds below zero once in ~1e8 samples and the sampled
+    direction is NaN. The reference then walks a poisoned shadow ray (every comparison with NaN is false: every object is accepted,
+    the last one -- spheres.json's emitter -- wins, Raytracer.cpp:115) and adds f * max(0, NaN) * Le / (NaN + pl) = NaN. Until round 4
+    the kernels skipped the sample on max(0, NaN) = 0: two pixels of the 1920 x 1080 x 16-pass frame were finite here and NaN in the
+    reference (found by comparing the WHOLE frame, tests/test_hip_workloads.py). The two paths, replayed: NaN in the oracle and in the
+    STRICT kernels, same final generator state."""
+    from oraclelib import OracleLib, available, camera_ray
+    if not available("oracle"):
+        pytest.skip("oracle not built")
+    sc = scenes["spheres_a169"]
+    h = OracleLib("oracle").create(sc, 1)
+    W, H, S, seed = 1920, 1080, 32, 0o715517
+    rays, states = np.zeros((2, 6), np.float32), np.zeros((2, 2), np.uint64)
+    for k, (x, y, npass, sample) in enumerate(((1805, 111, 8, 10), (527, 355, 11, 10))):
+        o, d, st = camera_ray(h, W, H, S, x, y, sample, npass=npass, seed=seed)
+        rays[k, :3], rays[k, 3:], states[k] = o, d, st
+    want, want_fin = h.shade(rays[:, :3], rays[:, 3:], states, depth_limit=8)
+    assert np.isnan(want).all()
+    with HipRenderer(sc, W, H, spp=S, depth_limit=8, seed=seed, strict=True) as r:
+        got, fin = r.kat_shade(rays[:, :3], rays[:, 3:], states)
+    assert np.isnan(got).all() and np.array_equal(fin, want_fin)

@@ -325,3 +325,29 @@ def test_configs0_c1_full_size_against_the_reference(scenes, golden):
         rmse = np.sqrt(np.mean(((np.clip(conv, 0, 1) - np.clip(ref_s, 0, 1)) ** 2)[m]))
         floor = np.sqrt(np.nanmean((np.clip(ref_s, 0, 1) - np.clip(ref_f, 0, 1)) ** 2))
         assert rmse <= max(1e-3, 1.5 * floor), (strict, rmse, floor)
+
+
+def test_configs1_whole_frame_strict_equals_oracle(scenes):
+    """BASELINE configs[1] exactly as bench.py times it -- 1920 x 1080, 16 passes x S = 32, depth 8, one launch -- and the WHOLE frame:
+    every one of the 2 073 600 pixels of the STRICT kernels' accumulation buffer equals the oracle's, bit for bit (the oracle takes
+    the host cores ~20 s for the 829 M paths); FAST over the whole frame is recorded beside it."""
+    import time
+    sc = scenes["spheres_a169"]
+    W, H, P = 1920, 1080, 16
+    t0 = time.time()
+    want = OracleLib("oracle").create(sc, 1).render(W, H, S=32, passes=P, seed=SEED, depth_limit=8, threads=THREADS)
+    t_oracle = time.time() - t0
+    with HipRenderer(sc, W, H, spp=32, depth_limit=8, seed=SEED, strict=True, passes_per_launch=16) as r:
+        got = r.render(P).radiance()
+    same = ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))[..., :3].all(-1)
+    assert same.all(), "%d of %d pixels differ" % (int((~same).sum()), same.size)
+    wantf = OracleLib("oracle").create(sc, 0).render(W, H, S=32, passes=P, seed=SEED, depth_limit=8, threads=THREADS)[..., :3] / P
+    with HipRenderer(sc, W, H, spp=32, depth_limit=8, seed=SEED, passes_per_launch=16) as r:
+        fast = r.render(P).radiance()[..., :3] / P
+    rm = clamped_rmse(fast, wantf)
+    off = int((np.abs(np.clip(fast, 0, 1) - np.clip(wantf, 0, 1)).max(-1) > 1e-3).sum())
+    record({"key": "configs[1] whole frame 1920x1080 x 16 passes", "strict_px_bit_identical_to_oracle": int(same.sum()), "px": int(same.size),
+            "fast_vs_oracle_libm_rmse_whole_frame": rm, "fast_px_off_by_more_than_1e-3": off, "oracle_seconds": round(t_oracle, 1), "oracle_threads": THREADS})
+    print("configs[1] whole frame: STRICT %d / %d px bit-identical; FAST clamped RMSE %.3g, %d px off by > 1e-3 (oracle %.1f s on %d threads)" % (
+        int(same.sum()), same.size, rm, off, t_oracle, THREADS))
+    assert rm < 1e-3

@@ -1477,7 +1477,19 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         const bool below = dot(vN, toC) < -(1.001f * lk.radius + 1e-6f * (__builtin_fabsf(toC.x) + __builtin_fabsf(toC.y) + __builtin_fabsf(toC.z)));
                         if (!(vKind == 2 || below))
                             break;
+#if KAJO_STRICT
+                        // (A light below the horizon adds nothing -- unless its sample is NOT A NUMBER, which the reference adds as NaN
+                        // when its poisoned shadow walk ends on that light (see the skip on the cosine further down). That needs
+                        // r^2 - x^2 - y^2 < 0, i.e. the sample's first uniform within rounding of 1: such a draw -- one in a million --
+                        // goes through the sampling code, where the case is decided; only the diffuse lobe's pdf is NaN for a NaN direction.)
+                        Rng peek = rng;
+                        rngStep(peek);
+                        if (vKind == 0 && unitBits((uint32_t)peek.lo) > 0.999999f)
+                            break;
+                        rng = peek;
+#else
                         rngStep(rng);
+#endif
                     }
                     if (k < nL) {
                         si = lds.light[k];
@@ -1617,7 +1629,19 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         const bool below = dot(vN, toC) < -(1.001f * lk.radius + 1e-6f * (__builtin_fabsf(toC.x) + __builtin_fabsf(toC.y) + __builtin_fabsf(toC.z)));
                         if (!(vKind == 2 || below))
                             break;
+#if KAJO_STRICT
+                        // (A light below the horizon adds nothing -- unless its sample is NOT A NUMBER, which the reference adds as NaN
+                        // when its poisoned shadow walk ends on that light (see the skip on the cosine further down). That needs
+                        // r^2 - x^2 - y^2 < 0, i.e. the sample's first uniform within rounding of 1: such a draw -- one in a million --
+                        // goes through the sampling code, where the case is decided; only the diffuse lobe's pdf is NaN for a NaN direction.)
+                        Rng peek = rng;
+                        rngStep(peek);
+                        if (vKind == 0 && unitBits((uint32_t)peek.lo) > 0.999999f)
+                            break;
+                        rng = peek;
+#else
                         rngStep(rng);
+#endif
                     }
                     if (lightK >= sc.nLights)
                         break;

@@ -235,3 +235,21 @@ def test_resolve_straight_from_tile_buffers(scenes):
             capi.check(L.kajo_hip_resolve_gathered_argb8_device(owners[1]._h, None, C.c_void_p(out.data_ptr())))
         for o in owners:
             o.close()
+
+
+def test_not_a_number_sample_of_a_light_below_the_horizon(scenes):
+    """The large-scene kernels pass over lights that lie wholly below a vertex's horizon (they only draw their number). One draw in a
+    million makes the sample's direction NaN (Light.cpp:43-46), and the reference then adds NaN when its poisoned shadow walk ends on
+    that light -- horizon or not. Pixel (827, 462) of the 1000-sphere scene at 1920 x 1080, 2 passes is such a case (found by
+    tools/whole_frame.py): NaN in the oracle, finite in the kernels until round 4. Lists and grid, against the oracle on the 16 x 8
+    pixels around it."""
+    from kajo_amd import capi
+    from kajo_amd.scene import stress_scene
+    sc = stress_scene(scenes["spheres_a169"], 1000, 16)
+    W, H, P, x0, y0 = 1920, 1080, 2, 819, 458
+    want = OracleLib("oracle").create(sc, 1).render(W, H, S=32, passes=P, seed=SEED, depth_limit=8, rect=(x0, y0, 16, 8), threads=8)[y0:y0 + 8, x0:x0 + 16, :3]
+    assert np.isnan(want[462 - y0, 827 - x0]).all()
+    for flags in (0, capi.KAJO_FLAG_NO_SHADOW_LISTS):
+        with HipRenderer(sc, W, H, spp=32, depth_limit=8, seed=SEED, strict=True, passes_per_launch=P, flags=flags) as r:
+            got = r.render(P).radiance()[y0:y0 + 8, x0:x0 + 16, :3]
+        assert ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))).all(), flags

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""STRICT kernels against the oracle over WHOLE frames of the BASELINE configs (not crops): how many pixels differ in a bit, where, and
+the NaN pixels on both sides. The oracle runs on the host cores (minutes for the big ones). usage: whole_frame.py [c2] [c3] [c4] [c5] [test]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
+import numpy as np, warnings
+warnings.filterwarnings("ignore")
+from kajo_amd.renderer import HipRenderer
+from kajo_amd.scene import Scene, stress_scene
+from oraclelib import OracleLib
+from bench import host_cores
+
+z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+a169 = Scene.from_npz(z, "spheres_a169/", "spheres.json 16:9")
+cases = {
+    "c2": ("configs[1] spheres.json 1920x1080 x 16", a169, 1920, 1080, 16, 16),
+    "c3": ("configs[2] spheres.json 3840x2160 x 64", a169, 3840, 2160, 64, 64),
+    "c4": ("configs[3] caustics 1920x1080 x 16 (of 128)", Scene.from_npz(z, "caustics_a169/", "caustics"), 1920, 1080, 16, 16),
+    "c5": ("configs[4] 1000 spheres / 16 lights 1920x1080 x 2", stress_scene(a169, 1000, 16), 1920, 1080, 2, 2),
+    "test": ("data/test.json 1024x1024 x 8", Scene.from_npz(z, "test_a1/", "test.json"), 1024, 1024, 8, 8),
+}
+import threading
+def _heartbeat():  # (a run that prints nothing for seven minutes is taken to be hung: the oracle needs minutes per frame)
+    t0 = time.time()
+    while True:
+        time.sleep(60)
+        print("  ... %d s" % (time.time() - t0), flush=True)
+threading.Thread(target=_heartbeat, daemon=True).start()
+SEED = 0o715517
+threads = max(1, min(host_cores(), 64))
+O = OracleLib("oracle")
+for key in (sys.argv[1:] or ["c2", "c4", "test"]):
+    name, sc, W, H, P, ppl = cases[key]
+    t0 = time.time()
+    want = O.create(sc, 1).render(W, H, S=32, passes=P, seed=SEED, depth_limit=8, threads=threads)
+    t_or = time.time() - t0
+    with HipRenderer(sc, W, H, spp=32, depth_limit=8, seed=SEED, strict=True, passes_per_launch=ppl) as r:
+        got = r.render(P).radiance()
+    a, b = got[..., :3], want[..., :3]
+    differ = ((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))).any(-1)
+    print("%-52s %9d px: %d differ; NaN px kernel %d oracle %d; oracle %.0f s on %d threads" % (
+        name, W * H, int(differ.sum()), int(np.isnan(a).any(-1).sum()), int(np.isnan(b).any(-1).sum()), t_or, threads), flush=True)
+    for y, x in np.argwhere(differ)[:8]:
+        print("     (%d, %d) kernel %s oracle %s" % (x, y, a[y, x], b[y, x]), flush=True)

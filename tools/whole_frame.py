@@ -19,6 +19,9 @@ cases = {
     "c4": ("configs[3] caustics 1920x1080 x 16 (of 128)", Scene.from_npz(z, "caustics_a169/", "caustics"), 1920, 1080, 16, 16),
     "c5": ("configs[4] 1000 spheres / 16 lights 1920x1080 x 2", stress_scene(a169, 1000, 16), 1920, 1080, 2, 2),
     "test": ("data/test.json 1024x1024 x 8", Scene.from_npz(z, "test_a1/", "test.json"), 1024, 1024, 8, 8),
+    "c4full": ("configs[3] caustics 1920x1080 x 128 (all of its 4096 spp)", Scene.from_npz(z, "caustics_a169/", "caustics"), 1920, 1080, 128, 16),
+    "dialect": ("dialect.json (every form of the scene dialect) 1024x1024 x 8", Scene.from_npz(z, "dialect_a1/", "dialect"), 1024, 1024, 8, 8),
+    "a43": ("spheres.json 4:3 1600x1200 x 16", Scene.from_npz(z, "spheres_a43/", "spheres 4:3"), 1600, 1200, 16, 16),
 }
 import threading
 def _heartbeat():  # (a run that prints nothing for seven minutes is taken to be hung: the oracle needs minutes per frame)

@@ -33,12 +33,17 @@ threading.Thread(target=_heartbeat, daemon=True).start()
 SEED = 0o715517
 threads = max(1, min(host_cores(), 64))
 O = OracleLib("oracle")
+# (name, scene, W, H, passes, passes per launch[, S, depth limit])
+cases["c1big"] = ("configs[0]'s settings (S = 16, one pass, 1 bounce) at 2048x2048", Scene.from_npz(z, "spheres_a1/", "spheres 1:1"), 2048, 2048, 1, 1, 16, 1)
+cases["c2alt"] = ("spheres.json 1920x1080, ONE pass of S = 512 (n = 22)", a169, 1920, 1080, 1, 1, 512, 8)
+cases["c2steal"] = ("spheres.json 1920x1080 x 7 passes in launches of 3 (split launches, taken-over passes)", a169, 1920, 1080, 7, 3)
 for key in (sys.argv[1:] or ["c2", "c4", "test"]):
-    name, sc, W, H, P, ppl = cases[key]
+    name, sc, W, H, P, ppl = cases[key][:6]
+    S, depth = (cases[key][6:] + (32, 8))[:2] if len(cases[key]) > 6 else (32, 8)
     t0 = time.time()
-    want = O.create(sc, 1).render(W, H, S=32, passes=P, seed=SEED, depth_limit=8, threads=threads)
+    want = O.create(sc, 1).render(W, H, S=S, passes=P, seed=SEED, depth_limit=depth, threads=threads)
     t_or = time.time() - t0
-    with HipRenderer(sc, W, H, spp=32, depth_limit=8, seed=SEED, strict=True, passes_per_launch=ppl) as r:
+    with HipRenderer(sc, W, H, spp=S, depth_limit=depth, seed=SEED, strict=True, passes_per_launch=ppl) as r:
         got = r.render(P).radiance()
     a, b = got[..., :3], want[..., :3]
     differ = ((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))).any(-1)

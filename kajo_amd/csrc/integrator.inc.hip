@@ -1159,9 +1159,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #define KAJO_PROF(k, cond)                                                                                             \
     do {                                                                                                               \
     } while (0)
+#ifdef KAJO_MARKS
+// (tools/isa_blocks.py: the blocks' boundaries as comments in the compiler's assembly output; not a build that runs)
+#define KAJO_STAMP(k) asm volatile("; KMARK " #k)
+#else
 #define KAJO_STAMP(k)                                                                                                  \
     do {                                                                                                               \
     } while (0)
+#endif
 #endif
 
 #ifdef KAJO_PROFILE

@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
 """STRICT kernels against the oracle over WHOLE frames of the BASELINE configs (not crops): how many pixels differ in a bit, where, and
-the NaN pixels on both sides. The oracle runs on the host cores (minutes for the big ones). usage: whole_frame.py [c2] [c3] [c4] [c5] [test]"""
+the NaN pixels on both sides. The oracle runs on the host cores (minutes for the big ones).
+usage: whole_frame.py [seed=<stream seed>] [c2] [c3] [c4] [c5] [test] ... [mix:<scene seed>] [stress:<spheres>:<lights>:<scene seed>]
+mix:<n> = a seeded small scene of this tool's own: the room of spheres.json with its planes' materials drawn anew (diffuse, Phong, ideal
+reflector), 8-20 spheres under ROTATED transforms (the general-sphere records) -- diffuse, Phong, mirror, glass of several indices --
+some of them overlapping, 1-4 lights of different sizes."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -31,13 +35,31 @@ def _heartbeat():  # (a run that prints nothing for seven minutes is taken to be
         print("  ... %d s" % (time.time() - t0), flush=True)
 threading.Thread(target=_heartbeat, daemon=True).start()
 SEED = 0o715517
+
+
+from scenes_extra import mixed_scene
 threads = max(1, min(host_cores(), 64))
 O = OracleLib("oracle")
 # (name, scene, W, H, passes, passes per launch[, S, depth limit])
 cases["c1big"] = ("configs[0]'s settings (S = 16, one pass, 1 bounce) at 2048x2048", Scene.from_npz(z, "spheres_a1/", "spheres 1:1"), 2048, 2048, 1, 1, 16, 1)
 cases["c2alt"] = ("spheres.json 1920x1080, ONE pass of S = 512 (n = 22)", a169, 1920, 1080, 1, 1, 512, 8)
 cases["c2steal"] = ("spheres.json 1920x1080 x 7 passes in launches of 3 (split launches, taken-over passes)", a169, 1920, 1080, 7, 3)
-for key in (sys.argv[1:] or ["c2", "c4", "test"]):
+keys = []
+for a in sys.argv[1:]:
+    if a.startswith("seed="):
+        SEED = int(a[5:], 0)
+    elif a.startswith("mix:"):
+        cases[a] = ("seeded small scene %s (rotated spheres, every material) 1920x1080 x 8" % a, mixed_scene(a169, int(a[4:])), 1920, 1080, 8, 8)
+        keys.append(a)
+    elif a.startswith("stress:"):
+        ns, nl, sd = (int(v) for v in a[7:].split(":"))
+        cases[a] = ("%d spheres / %d lights (scene seed %d) 1280x720 x 2" % (ns, nl, sd), stress_scene(a169, ns, nl, seed=sd), 1280, 720, 2, 2)
+        keys.append(a)
+    else:
+        keys.append(a)
+if SEED != 0o715517:
+    print("# stream seed %d" % SEED, flush=True)
+for key in (keys or ["c2", "c4", "test"]):
     name, sc, W, H, P, ppl = cases[key][:6]
     S, depth = (cases[key][6:] + (32, 8))[:2] if len(cases[key]) > 6 else (32, 8)
     t0 = time.time()

@@ -67,6 +67,8 @@ extern "C" {
 #define KAJO_FLAG_NO_SPLIT 16u  /* small frames: do not let several waves share a pixel block and divide the passes */
 #define KAJO_FLAG_NO_SHADOW_LISTS 128u /* large scenes: shadow rays walk the uniform grid as extension rays do, instead of being answered
                                    from the lights' visibility lists inside the light loop (same results; for A/B runs and tests) */
+#define KAJO_FLAG_NO_ONE_LIGHT 256u /* small scenes with exactly one light, FAST numerics: run the kernel instance of any number of lights
+                                   instead of the one that samples the BSDF in the light's visit (same results; for A/B runs and tests) */
 
 typedef struct KajoParams {
     int32_t samplesPerPass; /* S: nominal samples per pixel per pass (reference: 32, Renderer.cpp:21);

@@ -672,8 +672,10 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream)
                                           : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream));
         } else {
-            le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream)
-                                          : kajo_render_fast_launch(&a, h->coldInLds, grid, block, ldsTotal, h->stream));
+            // (coldInLds 2: the small-scene instance of any number of lights although the scene has one, KAJO_FLAG_NO_ONE_LIGHT)
+            const int home = (h->coldInLds && (h->params.flags & KAJO_FLAG_NO_ONE_LIGHT)) ? 2 : h->coldInLds;
+            le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, home, grid, block, ldsTotal, h->stream)
+                                          : kajo_render_fast_launch(&a, home, grid, block, ldsTotal, h->stream));
         }
         if (le != hipSuccess) {
             h->eventPool.push_back(e0);

@@ -1022,7 +1022,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
 // light's visibility lists (lightReached) instead of costing the lane a trip of its own through the grid: the light loop of a
 // vertex runs to its end in ONE trip, as Shader::sampleLights does (Shader.cpp:50-86), and every trip's walk carries camera and
 // extension rays only. Same draws, same tests, same sums in the same order: the buffer does not change by a bit.
-template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool LISTS = false>
+template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool LISTS = false, bool ONE_LIGHT = false>
 KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 {
     const DSceneView& sc = args.scene;
@@ -1134,6 +1134,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     unsigned long long ctrTraversals = 0, ctrVertices = 0, ctrSlots = 0, ctrShadow = 0;
     const bool counting = args.counters != nullptr;
+    // (FAST, small scenes of ONE light -- the kernel instance launched for them: the extension ray is sampled in the same visit of
+    // the light / BSDF blocks as the light)
+    constexpr bool PRESAMPLE = ONE_LIGHT && !KAJO_STRICT && COLD_LDS && !LISTS;
 #ifdef KAJO_PROFILE
     // block profile: prof[2k] = wave executions of block k, prof[2k+1] = lanes active in it
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1406,15 +1409,32 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             }
         } else if (!LISTS && mode == MODE_SHADOW) {
             // Shader.cpp:72-73: the sample counts iff the closest hit of the shadow ray IS the light
-            if (hit.id == np + 1 + lds.light[lightK]) {
+            const bool pre = PRESAMPLE && lightK < 0; // the extension ray was sampled together with this (the vertex's last) light
+            const int lk = pre ? ~lightK : lightK;
+            if (hit.id == np + 1 + lds.light[lk]) {
 #if KAJO_STRICT
                 vLd = vLd + pendContrib;
 #else
                 vE = vE + pendContrib;
 #endif
             }
-            lightK++;
-            sampleNext = true;
+            if (pre) {
+#if !KAJO_STRICT
+                // ... and waits in the vertex's dead registers: direction in vN, path-weight factor in vR (see the BSDF sampling block)
+                const DFloat4 v4 = reinterpret_cast<const DFloat4*>(lds.material + (vId - 1))[4];
+                L = L + T * ((vKind == 0 ? v4.x : v4.y) * vE);
+                T = T * vR;
+                O = vP + vN * kEps;
+                d = vN;
+                if (pendP == 0.0f)
+                    pathDone = true;
+                else
+                    mode = MODE_EXTEND;
+#endif
+            } else {
+                lightK++;
+                sampleNext = true;
+            }
         }
 
         KAJO_STAMP(2); // vertex / shadow-result block
@@ -1713,8 +1733,16 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 shadowRay = true;
                 break;
             }
-            KAJO_PROF(7, !shadowRay);
-            if (!shadowRay) {
+            // FAST, small scenes with one light (a kernel instance of their own: with several lights only the last light's visit
+            // could take the BSDF along, which measured a loss -- profiles/r04_presample.txt): the extension ray is sampled in this
+            // visit too (the random numbers come in the reference's order either way: the light's draw, then the BSDF's) and waits
+            // out the shadow ray's trip in the registers of the vertex's normal and reflection vector, which nothing reads again.
+            // The block then runs once per vertex instead of twice -- each visit with the lanes of both halves -- where it ran
+            // with a fifth of the lanes per half; the arithmetic, and so every bit of the result, is the same. (STRICT walks the
+            // shadow ray inside the light loop and has had the one visit since then.)
+            const bool presample = PRESAMPLE && shadowRay;
+            KAJO_PROF(7, !shadowRay || presample);
+            if (!shadowRay || presample) {
                 // ---- BSDF sampling (Shader.cpp:191-200) ------------------------------------------
                 F3 tg = f3(0.0f, 0.0f, 0.0f), bn = tg;
                 if (vKind == 0) {
@@ -1728,31 +1756,47 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
                 float p;
                 F3 fd;
-                d = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
 #if KAJO_STRICT
+                d = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
                 L = L + T * (vSl * (vE + vLd));
                 vS = vSl;
-#else
-                L = L + T * (vSl * vE);
-#endif
                 // The next segment's state is written unconditionally: a path that ends here (p == 0) re-initialises
                 // all of it when its lane starts the next camera path, and unconditional writes need no copies.
                 pendP = p;
                 pendBsdf = true;
-#if KAJO_STRICT
                 pendF = fd;
                 pendCos = kmax0(dot(vN, d));
                 pendT = T;
                 T = T * (vSl * ((krcp(0.0f + p) * pendF) * pendCos));
-#else
-                T = T * (vSl * ((krcp(p) * fd) * kmax0(dot(vN, d))));
-#endif
                 O = vP + d * kEps;
                 depth++;
                 if (p == 0.0f)
                     pathDone = true;
                 else
                     mode = MODE_EXTEND;
+#else
+                const F3 dB = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
+                const F3 w = vSl * ((krcp(p) * fd) * kmax0(dot(vN, dB)));
+                pendP = p;
+                pendBsdf = true;
+                depth++;
+                if (presample) { // the shadow ray goes first (O, d hold it); the shadow-result block takes it from here
+                    vN = dB;
+                    vR = w;
+                    lightK = ~lightK;
+                } else {
+                    L = L + T * (vSl * vE);
+                    // The next segment's state is written unconditionally: a path that ends here (p == 0) re-initialises
+                    // all of it when its lane starts the next camera path, and unconditional writes need no copies.
+                    T = T * w;
+                    O = vP + dB * kEps;
+                    d = dB;
+                    if (p == 0.0f)
+                        pathDone = true;
+                    else
+                        mode = MODE_EXTEND;
+                }
+#endif
             }
         }
 
@@ -1837,11 +1881,27 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 } // namespace
 
 // whole scene in LDS
+#ifdef KAJO_KERNEL_NAME_LIGHTS
+// (FAST: scenes with exactly one light have an instance of their own, see PRESAMPLE; it carries the mode's plain name because it is
+// the one the headline workload runs)
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<true, false, false, false, true>(args, ldsRaw);
+}
+
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_LIGHTS(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<true, false>(args, ldsRaw);
+}
+#else
 extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBody<true, false>(args, ldsRaw);
 }
+#endif
 
 // small frames: the workgroup's waves share one pixel block and divide the passes (see renderBody)
 extern "C" __global__ void __launch_bounds__(1024, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_SPLIT(const RenderArgs args)

@@ -4,6 +4,12 @@
 #define KAJO_WAVES_PER_SIMD 5 // the FAST loop fits 96 VGPRs without spills (tools/vgpr_check.sh)
 #endif
 #define KAJO_KERNEL_NAME kajo_render_fast
+#ifndef KAJO_PRESAMPLE
+#define KAJO_PRESAMPLE 1
+#endif
+#if KAJO_PRESAMPLE
+#define KAJO_KERNEL_NAME_LIGHTS kajo_render_fast_lights // small scenes with several lights (or none); kajo_render_fast: exactly one
+#endif
 #define KAJO_KERNEL_NAME_BIG kajo_render_fast_big
 #define KAJO_KERNEL_NAME_BIGLIST kajo_render_fast_biglist
 #define KAJO_KERNEL_NAME_SPLIT kajo_render_fast_split

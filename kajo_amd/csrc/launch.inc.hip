@@ -2,11 +2,16 @@
 #define KAJO_CAT2(a, b) a##b
 #define KAJO_CAT(a, b) KAJO_CAT2(a, b)
 
-// coldInLds: 1 = whole scene staged in LDS (KAJO_KERNEL_NAME), 0 = cold records stay global (the scene's shadow.enabled picks
-// the kernel that answers shadow queries from the lights' visibility lists)
+// coldInLds: 1 = whole scene staged in LDS (KAJO_KERNEL_NAME; FAST: its one-light instance for scenes of one light, 2 = never that one),
+// 0 = cold records stay global (the scene's shadow.enabled picks the kernel that answers shadow queries from the lights' visibility lists)
 extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _launch)(const RenderArgs* args, int coldInLds, unsigned grid, unsigned block,
                                                 size_t ldsBytes, void* stream)
 {
+#ifdef KAJO_KERNEL_NAME_LIGHTS
+    if (coldInLds && (args->scene.nLights != 1 || coldInLds == 2))
+        hipLaunchKernelGGL(KAJO_KERNEL_NAME_LIGHTS, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
+    else
+#endif
     if (coldInLds)
         hipLaunchKernelGGL(KAJO_KERNEL_NAME, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
     else if (args->scene.shadow.enabled)
@@ -35,6 +40,10 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(int coldInLds, size_t ldsByt
     hipError_t e;
     if (coldInLds) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+#ifdef KAJO_KERNEL_NAME_LIGHTS
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME_LIGHTS), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+#endif
     } else {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIG), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e == hipSuccess)

@@ -116,7 +116,7 @@ struct KajoHip
     int stealWindow = 4; // render_args.h; 1 when a large scene needs the LDS for its grid
     int thrL = 1, holdTrips = 1; // integrator.inc.hip MODE_HOLD
     int ldsExtra = 0;    // (KAJO_TUNING builds only) unused bytes per wave, to study a launch at a lower occupancy
-    int helpBytes = 0;   // behind the mailbox. List scenes: [64] owner lanes + [64] blocker flags of the cooperative list walk; small FAST scenes of one light: KAJO_QUEUE_BYTES (integrator.inc.hip)
+    int helpBytes = 0;   // list scenes: [64] owner lanes + [64] blocker flags of the cooperative list walk (integrator.inc.hip), behind the mailbox
     size_t perWaveBytes(bool withMailbox) const { return (size_t)ldsExtra + (size_t)helpBytes + (withMailbox ? (size_t)64 * stealWindow * 16 : 0); }
     void fillWaveLds(RenderArgs& a, size_t perWaveOffset, bool withMailbox) const
     {
@@ -420,8 +420,6 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     const bool big = st.gridEnabled || hotBytes + coldBytes > 40 * 1024;
     h->stealWindow = 4;
     h->helpBytes = st.shadowEnabled ? 512 : 0;
-    if (!big && !h->strict() && v.nLights == 1)
-        h->helpBytes = KAJO_QUEUE_BYTES; // the one-light FAST instance's stack of shadow-ray jobs (render_args.h)
     KAJO_TUNE_INT("KAJO_STEAL_WINDOW", 1, 16, h->stealWindow);
     KAJO_TUNE_INT("KAJO_LDS_EXTRA", 0, 64 * 1024, h->ldsExtra);
     h->ldsExtra &= ~15;

@@ -1138,30 +1138,6 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // (FAST, small scenes of ONE light -- the kernel instance launched for them: the extension ray is sampled in the same visit of
     // the light / BSDF blocks as the light)
     constexpr bool PRESAMPLE = ONE_LIGHT && !KAJO_STRICT && COLD_LDS && !LISTS;
-#ifndef KAJO_SHADOW_QUEUE
-#define KAJO_SHADOW_QUEUE 1
-#endif
-    // ... and its shadow rays are JOBS for lanes that have no ray of their own in a trip (vertices waiting for the light / BSDF
-    // blocks, lanes that are done): the lane that sampled the light leaves (ray, weighted contribution, pixel lane) on a per-wave
-    // stack in LDS and goes on with its extension ray at once; a lane without a ray takes a job before the walk and, if the ray
-    // reached the light, adds the contribution to the pixel's late sum in LDS, which joins the pixel's total when the wave ends.
-    // A shadow ray then costs no lane a trip of its own as long as the wave has idle slots (0.22 per path against 0.16 shadow
-    // rays on spheres.json); the stack full, the lane walks its shadow ray itself as before. Per wave: KAJO_QUEUE_BYTES behind
-    // the mailbox (capi.cpp queueBytes): control words, late sums [3][64], KAJO_QUEUE_JOBS jobs of three float4.
-    constexpr bool QUEUE = PRESAMPLE && KAJO_SHADOW_QUEUE;
-    // (volatile through a GENERIC pointer compiles to flat_load / flat_store with system scope and a vmcnt(0) wait each -- the compiler
-    // does not infer the address space for volatile accesses; the LDS address space is spelled out)
-    KajoLdsWord* qctrl = (KajoLdsWord*)(reinterpret_cast<unsigned char*>(mailbox) + 64 * stealWindow * 16); // [0] jobs on the stack
-    float* qlate = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(mailbox) + 64 * stealWindow * 16 + 16);
-    DFloat4* qjobs = reinterpret_cast<DFloat4*>(qlate + 3 * 64);
-    if (QUEUE) {
-        if (lane < 4)
-            qctrl[lane] = 0u;
-        qlate[lane] = 0.0f;
-        qlate[64 + lane] = 0.0f;
-        qlate[128 + lane] = 0.0f;
-        __builtin_amdgcn_wave_barrier();
-    }
 #ifdef KAJO_PROFILE
     // block profile: prof[2k] = wave executions of block k, prof[2k+1] = lanes active in it
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1321,54 +1297,17 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             }
         }
         int aliveCount;
-        int qTop = 0, qTaken = 0; // (wave-uniform) jobs on the stack before this trip's takers, and how many they take
         {
             const unsigned long long aliveMask = __ballot(mode != MODE_DONE);
-            if (QUEUE)
-                qTop = __builtin_amdgcn_readfirstlane((int)qctrl[0]);
-            if (aliveMask == 0ull && qTop == 0)
+            if (aliveMask == 0ull)
                 break;
             aliveCount = __builtin_popcountll(aliveMask);
         }
-        bool jobTaken = false;
-        if (QUEUE && qTop != 0) {
-            const bool idle = !(mode == MODE_EXTEND || mode == MODE_SHADOW);
-            const unsigned long long idleMask = __ballot(idle);
-            const int nIdle = __builtin_popcountll(idleMask);
-            qTaken = nIdle < qTop ? nIdle : qTop;
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
-            jobTaken = idle && rank < qTaken;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); // (the jobs were written by other lanes of the wave, in an earlier trip)
-            if (jobTaken) { // (O and d of a lane without a ray are dead: the blocks that give it its next ray write both)
-                const DFloat4* job = qjobs + 3 * (qTop - 1 - rank);
-                const DFloat4 j0 = job[0], j1 = job[1];
-                O = f3(j0.x, j0.y, j0.z);
-                d = f3(j0.w, j1.x, j1.y);
-            }
-            if (lane == 0)
-                qctrl[0] = (uint32_t)(qTop - qTaken);
-        }
-        const unsigned long long activeMask = __ballot(mode == MODE_EXTEND || mode == MODE_SHADOW || jobTaken); // lanes with a ray
+        const unsigned long long activeMask = __ballot(mode == MODE_EXTEND || mode == MODE_SHADOW); // lanes with a ray
 
         KAJO_STAMP(0); // camera-ray block
         // ---- one ray per lane through the whole scene ------------------------------------------
         const Hit hit = trace<!COLD_LDS>(sc, lds, O, d, mode == MODE_EXTEND || mode == MODE_SHADOW);
-        if (QUEUE && qTaken != 0) {
-            // the jobs' answers (Shader.cpp:72-73: the sample counts iff the closest hit of the shadow ray IS the light)
-            const bool idle = !(mode == MODE_EXTEND || mode == MODE_SHADOW);
-            const unsigned long long idleMask = __ballot(idle);
-            const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(idleMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idleMask, 0u));
-            if (idle && rank < qTaken && hit.id == np + 1 + lds.light[0]) {
-                const DFloat4* job = qjobs + 3 * (qTop - 1 - rank);
-                const DFloat4 j1 = job[1], j2 = job[2];
-                const float cx = j1.z, cy = j1.w, cz = j2.x;
-                const uint32_t dest = __builtin_bit_cast(uint32_t, j2.y);
-                __hip_atomic_fetch_add(qlate + dest, cx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(qlate + 64 + dest, cy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                __hip_atomic_fetch_add(qlate + 128 + dest, cz, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
         KAJO_STAMP(1); // traversal
         if (counting) {
             ctrTraversals += __builtin_popcountll(activeMask);
@@ -1545,7 +1484,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             // a wave makes as many item rounds as its longest list has items, and without help a third of the lanes would walk
             // lists of 5 items on average and 13 at the longest while the rest watch. Which lane tests an item does not change the
             // test; the owner adds its contribution iff nobody found a blocker: the sums form as before, in light order.
-            // (the LDS address space spelled out: volatile accesses through a generic pointer are flat, system-scope, vmcnt(0)-waited)
+            // (The LDS address space spelled out: the compiler does not infer it for VOLATILE accesses, and through a generic pointer they
+            // compile to flat_load / flat_store with system scope and a vmcnt(0) wait each -- in every round of this loop, until round 4
+            // looked: +1.4 % FAST, +0.9 % STRICT on the 1000-sphere scene.)
             KajoLdsWord* helpOwner = (KajoLdsWord*)(reinterpret_cast<unsigned char*>(mailbox) + 64 * stealWindow * 16);
             KajoLdsWord* helpFlag = helpOwner + 64;
             const uint2* items = reinterpret_cast<const uint2*>(sc.shadow.items);
@@ -1772,13 +1713,6 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 const DFloat4 le = lds.lightEmission[lightK];
                 const F3 Le = f3(le.x, le.y, le.z);
                 pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
-#ifdef KAJO_FREE_SHADOW
-                if (PRESAMPLE) { // TIMING EXPERIMENT (wrong images): shadow rays cost nothing -- the ceiling of handing them to idle lanes
-                    vE = vE + pendContrib;
-                    lightK++;
-                    continue;
-                }
-#endif
 #if KAJO_INLINE_SHADOW
                 if (!LISTS && COLD_LDS && !KAT && !SPLIT) {
                     // Small scenes, STRICT build: the shadow ray walks the scene right here (the closest-hit walk itself, so the
@@ -1852,28 +1786,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 pendP = p;
                 pendBsdf = true;
                 depth++;
-                bool queued = false;
-                if (QUEUE) {
-                    const unsigned long long pushMask = __ballot(presample);
-                    if (pushMask != 0ull) {
-                        const int have = __builtin_amdgcn_readfirstlane((int)qctrl[0]);
-                        const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(pushMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pushMask, 0u));
-                        queued = presample && have + rank < KAJO_QUEUE_JOBS;
-                        if (queued) { // O, d: the shadow ray; its contribution with the path's weight up to here
-                            const F3 c = T * (vSl * pendContrib);
-                            DFloat4* job = qjobs + 3 * (have + rank);
-                            job[0] = DFloat4{O.x, O.y, O.z, d.x};
-                            job[1] = DFloat4{d.y, d.z, c.x, c.y};
-                            job[2] = DFloat4{c.z, __builtin_bit_cast(float, (uint32_t)(stolenFrom >= 0 ? stolenFrom : lane)), 0.0f, 0.0f};
-                            if (rank == 0) {
-                                const int n = __builtin_popcountll(pushMask);
-                                qctrl[0] = (uint32_t)(have + n < KAJO_QUEUE_JOBS ? have + n : KAJO_QUEUE_JOBS);
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    }
-                }
-                if (presample && !queued) { // the shadow ray goes first (O, d hold it); the shadow-result block takes it from here
+                if (presample) { // the shadow ray goes first (O, d hold it); the shadow-result block takes it from here
                     vN = dB;
                     vR = w;
                 } else {
@@ -1940,10 +1853,6 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             const DFloat4 t = mailbox[lane * stealWindow + (p - stealBase)];
             total = total + f3(t.x, t.y, t.z);
         }
-#if !KAJO_STRICT
-        if (QUEUE) // the light samples whose shadow rays other lanes walked, of every pass of this launch
-            total = total + f3(qlate[lane], qlate[64 + lane], qlate[128 + lane]) * invS;
-#endif
         reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
     }
     if (!KAT && !SPLIT && args.waveTrips && lane == 0)

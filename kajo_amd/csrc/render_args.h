@@ -6,11 +6,6 @@
 
 #include "device_scene.h"
 
-// FAST, small scenes of one light: the per-wave stack of shadow-ray jobs (integrator.inc.hip QUEUE), behind the wave's mailbox:
-// control words (16 B), late sums [3][64] float, KAJO_QUEUE_JOBS jobs of three float4
-#define KAJO_QUEUE_JOBS 32
-#define KAJO_QUEUE_BYTES (16 + 3 * 64 * 4 + KAJO_QUEUE_JOBS * 48)
-
 struct RenderArgs
 {
     DSceneView scene;

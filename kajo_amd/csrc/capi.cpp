@@ -428,9 +428,10 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     h->thrL = big ? 1 : (h->strict() ? 28 : 20);
     h->holdTrips = 1;
     if (!big && h->strict()) {
-        // the STRICT loop of small scenes walks its shadow rays inside the light loop (KAJO_INLINE_SHADOW): a heavier block, worth
-        // waiting longer for (spheres.json: 19.15 G paths/s at 28 lanes / one trip, 19.85 at 44 / two; three lights: 11.6 -> 13.4 at 48 / three)
-        h->thrL = v.nLights > 1 ? 48 : 44;
+        // the STRICT loop of small scenes with several lights walks its shadow rays inside the light loop (KAJO_INLINE_SHADOW): a heavier
+        // block, worth waiting longer for (three lights: 11.6 -> 13.4 G paths/s at 48 lanes / three trips). One light (its own instance:
+        // one visit per vertex, the shadow ray in a trip of its own): 20.5-20.7 at 32-44 lanes / two trips (profiles/r04_presample.txt).
+        h->thrL = v.nLights > 1 ? 48 : 36;
         h->holdTrips = v.nLights > 1 ? 3 : 2;
     }
     if (st.shadowEnabled) {

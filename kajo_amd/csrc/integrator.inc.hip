@@ -1135,9 +1135,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
     unsigned long long ctrTraversals = 0, ctrVertices = 0, ctrSlots = 0, ctrShadow = 0;
     const bool counting = args.counters != nullptr;
-    // (FAST, small scenes of ONE light -- the kernel instance launched for them: the extension ray is sampled in the same visit of
-    // the light / BSDF blocks as the light)
-    constexpr bool PRESAMPLE = ONE_LIGHT && !KAJO_STRICT && COLD_LDS && !LISTS;
+    // Small scenes of ONE light --
+    // the kernel instance launched for them: the extension ray is sampled in the same visit of the light / BSDF blocks as the light.
+    // (STRICT too since its round-4 measurement: with ONE visit per vertex the shadow ray in a trip of its own -- the shared walk at
+    // 88 % of the lanes -- beats the walk inside the light loop at 55 %: 19.9 -> 20.5 G paths/s, profiles/r04_presample.txt.)
+    constexpr bool PRESAMPLE = ONE_LIGHT && COLD_LDS && !LISTS;
 #ifdef KAJO_PROFILE
     // block profile: prof[2k] = wave executions of block k, prof[2k+1] = lanes active in it
     unsigned long long prof[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1420,7 +1422,18 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #endif
             }
             if (pre) {
-#if !KAJO_STRICT
+#if KAJO_STRICT
+                // ... and waits in the register of the vertex's normal; the weight is formed here from its pieces, which wait for
+                // the next hit's MIS correction anyway (the expressions of the BSDF sampling block, in its order)
+                L = L + T * (vS * (vE + vLd));
+                T = T * (vS * ((krcp(0.0f + pendP) * pendF) * pendCos));
+                O = vP + vN * kEps;
+                d = vN;
+                if (pendP == 0.0f)
+                    pathDone = true;
+                else
+                    mode = MODE_EXTEND;
+#else
                 // ... and waits in the vertex's dead registers: direction in vN, path-weight factor in vR (see the BSDF sampling block)
                 const DFloat4 v4 = reinterpret_cast<const DFloat4*>(lds.material + (vId - 1))[4];
                 L = L + T * ((vKind == 0 ? v4.x : v4.y) * vE);
@@ -1714,7 +1727,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 const F3 Le = f3(le.x, le.y, le.z);
                 pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
 #if KAJO_INLINE_SHADOW
-                if (!LISTS && COLD_LDS && !KAT && !SPLIT) {
+                if (!LISTS && COLD_LDS && !KAT && !SPLIT && !PRESAMPLE) {
                     // Small scenes, STRICT build: the shadow ray walks the scene right here (the closest-hit walk itself, so the
                     // answer is the walk's by construction) instead of costing its lane a trip of its own: with the blocks held
                     // until args.thrL lanes want them the walk runs for those lanes at once. STRICT +6.4 % on spheres.json, +20 %
@@ -1763,23 +1776,28 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 float p;
                 F3 fd;
 #if KAJO_STRICT
-                d = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
-                L = L + T * (vSl * (vE + vLd));
+                const F3 dB = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
                 vS = vSl;
                 // The next segment's state is written unconditionally: a path that ends here (p == 0) re-initialises
                 // all of it when its lane starts the next camera path, and unconditional writes need no copies.
                 pendP = p;
                 pendBsdf = true;
                 pendF = fd;
-                pendCos = kmax0(dot(vN, d));
+                pendCos = kmax0(dot(vN, dB));
                 pendT = T;
-                T = T * (vSl * ((krcp(0.0f + p) * pendF) * pendCos));
-                O = vP + d * kEps;
                 depth++;
-                if (p == 0.0f)
-                    pathDone = true;
-                else
-                    mode = MODE_EXTEND;
+                if (presample) { // the shadow ray goes first (O, d hold it); the shadow-result block takes it from here
+                    vN = dB;
+                } else {
+                    L = L + T * (vSl * (vE + vLd));
+                    T = T * (vSl * ((krcp(0.0f + p) * pendF) * pendCos));
+                    O = vP + dB * kEps;
+                    d = dB;
+                    if (p == 0.0f)
+                        pathDone = true;
+                    else
+                        mode = MODE_EXTEND;
+                }
 #else
                 const F3 dB = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
                 const F3 w = vSl * ((krcp(p) * fd) * kmax0(dot(vN, dB)));

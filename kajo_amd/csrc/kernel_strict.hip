@@ -4,6 +4,12 @@
 #define KAJO_INLINE_SHADOW 1 // small scenes answer shadow rays inside the light loop (integrator.inc.hip)
 #endif
 #define KAJO_KERNEL_NAME kajo_render_strict
+#ifndef KAJO_STRICT_PRESAMPLE
+#define KAJO_STRICT_PRESAMPLE 1 // small scenes of ONE light: their own instance, shadow ray in a trip of its own with the BSDF sampled in the light's visit
+#endif
+#if KAJO_STRICT_PRESAMPLE
+#define KAJO_KERNEL_NAME_LIGHTS kajo_render_strict_lights // small scenes with several lights (or none): shadow walks inside the light loop
+#endif
 #define KAJO_KERNEL_NAME_BIG kajo_render_strict_big
 #define KAJO_KERNEL_NAME_BIGLIST kajo_render_strict_biglist
 #define KAJO_KERNEL_NAME_SPLIT kajo_render_strict_split

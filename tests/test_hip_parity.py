@@ -157,11 +157,13 @@ def test_shadow_lists_equal_the_grid_walk(O, scenes):
             assert a["vertices"] == b["vertices"]
 
 
-def test_one_light_kernel_equals_the_general_one(scenes):
-    """FAST, small scenes with exactly one light run a kernel instance that samples the extension ray in the same visit of the
-    light / BSDF blocks as the light (integrator.inc.hip PRESAMPLE) -- one visit per vertex instead of two. Same draws in the same
-    order, same arithmetic: the buffer is the general instance's (KAJO_FLAG_NO_ONE_LIGHT) bit for bit, on every one-light scene,
-    whole launches and split ones, every depth limit; walks and vertices counted the same."""
+@pytest.mark.parametrize("strict", [False, True])
+def test_one_light_kernel_equals_the_general_one(scenes, strict):
+    """Small scenes with exactly one light run a kernel instance that samples the extension ray in the same visit of the
+    light / BSDF blocks as the light (integrator.inc.hip PRESAMPLE) -- one visit per vertex instead of two (FAST), and the shadow
+    ray in a trip of its own instead of a walk inside the light loop (STRICT). Same draws in the same order, same arithmetic: the
+    buffer is the general instance's (KAJO_FLAG_NO_ONE_LIGHT) bit for bit, on every one-light scene, whole launches and split ones,
+    every depth limit; vertices counted the same, and every shadow ray counted as a walk of the one kind or the other."""
     from kajo_amd import capi
     for key, W, H, S, passes, ppl, depth in (("spheres_a169", 320, 180, 32, 5, 2, 8), ("spheres_a1", 128, 128, 16, 1, 1, 1), ("test_a1", 160, 160, 9, 3, 0, 8),
                                              ("dialect_a1", 97, 61, 4, 4, 3, 3), ("spheres_a43", 200, 150, 32, 2, 0, 2)):
@@ -169,11 +171,12 @@ def test_one_light_kernel_equals_the_general_one(scenes):
         assert sc.n_lights == 1, key
         got = {}
         for flags in (0, capi.KAJO_FLAG_NO_ONE_LIGHT, capi.KAJO_FLAG_NO_ONE_LIGHT | capi.KAJO_FLAG_NO_SPLIT, capi.KAJO_FLAG_NO_SPLIT):
-            with HipRenderer(sc, W, H, spp=S, seed=SEED, depth_limit=depth, strict=False, counters=True, flags=flags, passes_per_launch=ppl) as r:
+            with HipRenderer(sc, W, H, spp=S, seed=SEED, depth_limit=depth, strict=strict, counters=True, flags=flags, passes_per_launch=ppl) as r:
                 got[flags] = (r.render(passes).radiance(), r.counters())
+        walks = lambda c: c["traversals"] + c["shadowQueries"]
         for flags in got:
-            assert bits_equal(got[0][0], got[flags][0]), (key, flags)
-            assert got[0][1]["traversals"] == got[flags][1]["traversals"] and got[0][1]["vertices"] == got[flags][1]["vertices"], (key, flags)
+            assert bits_equal(got[0][0], got[flags][0]), (key, strict, flags)
+            assert walks(got[0][1]) == walks(got[flags][1]) and got[0][1]["vertices"] == got[flags][1]["vertices"], (key, strict, flags, got[0][1], got[flags][1])
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])

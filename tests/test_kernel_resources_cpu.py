@@ -1,0 +1,87 @@
+"""What the compiler made of the FAST kernels, checked without a GPU (hipcc cross-compiles gfx950): the register budgets the launch
+bounds promise, no spills in the small-scene loops, and no FLAT memory instruction anywhere in the translation unit.
+
+Why a test: both have regressed silently before. A `volatile` access through a generic pointer compiles to `flat_load` /
+`flat_store` with system scope and a `vmcnt(0)` wait (the compiler does not infer the LDS address space for volatile accesses) --
+the large-scene kernels' list walk carried five of those per round for most of round 4 -- and one more scalar value live across the
+small-scene loop spills five registers (-1.4 %). The command is the Makefile's own (`make -n`), with the
+assembly and the resource remarks asked for instead of an object file."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "kajo_amd", "csrc")
+
+
+def _compile(unit):
+    if shutil.which("hipcc") is None or shutil.which("make") is None:
+        pytest.skip("hipcc / make not available")
+    obj = os.path.join(CSRC, "build", "kernel_%s.o" % unit)
+    plan = subprocess.run(["make", "-n", "-B", "-C", CSRC, obj], capture_output=True, text=True, check=True).stdout
+    cmd = next(l for l in plan.splitlines() if l.startswith("hipcc") and "kernel_%s.hip" % unit in l).split()
+    tmp = tempfile.mkdtemp(prefix="kajo_res_")
+    asm = os.path.join(tmp, "k.s")
+    i = cmd.index("-c")
+    cmd = cmd[:i] + ["-S", "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage"] + cmd[i + 1:]
+    cmd[cmd.index("-o") + 1] = asm
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res, name = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            res[name] = {}
+            continue
+        m = re.search(r"remark:\s+(VGPRs|SGPRs Spill|VGPRs Spill|Occupancy \[waves/SIMD\]|ScratchSize \[bytes/lane\]): (\d+)", line)
+        if m and name:
+            res[name][m.group(1).split(" [")[0]] = int(m.group(2))
+    text = open(asm).read()
+    shutil.rmtree(tmp, ignore_errors=True)
+    return res, text
+
+
+def test_fast_kernels_keep_their_register_budgets_and_use_no_flat_accesses():
+    res, asm = _compile("fast")
+    # the two small-scene instances and the small-frame kernel: five waves per SIMD (96 VGPRs), nothing spilled
+    for k in ("kajo_render_fast", "kajo_render_fast_lights", "kajo_render_fast_split"):
+        assert k in res, sorted(res)
+        r = res[k]
+        assert r["Occupancy"] == 5 and r["VGPRs"] <= 96, (k, r)
+        assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0 and r["ScratchSize"] == 0, (k, r)
+    # the large-scene kernels: four waves per SIMD; they spill scalars, vector spills stay a handful
+    for k in ("kajo_render_fast_big", "kajo_render_fast_biglist"):
+        r = res[k]
+        assert r["Occupancy"] == 4 and r["VGPRs"] <= 128 and r["VGPRs Spill"] <= 8, (k, r)
+    # every pointer of these kernels has a known home (LDS or global): a flat access is an address space the compiler could not infer
+    flat = [l.strip() for l in asm.splitlines() if re.match(r"\s+flat_(load|store|atomic)", l)]
+    assert not flat, flat[:5]
+    # ... and the cross-lane words of the list walk are LDS instructions, not scratch or global ones
+    body = asm[asm.index("kajo_render_fast_biglist:"):]
+    body = body[:body.index("s_endpgm")]
+    assert "ds_bpermute_b32" in body and "ds_write_b32" in body
+
+
+def test_strict_kernels_keep_their_register_budgets():
+    res, asm = _compile("strict")
+    # small scenes: four waves per SIMD, no vector spills (the scalar ones are loop-invariant values parked in a VGPR's lanes)
+    for k in ("kajo_render_strict", "kajo_render_strict_lights", "kajo_render_strict_split"):
+        assert k in res, sorted(res)
+        r = res[k]
+        assert r["Occupancy"] == 4 and r["VGPRs"] <= 128 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0, (k, r)
+        body = asm[asm.index(k + ":"):]
+        body = body[:body.index("s_endpgm")]
+        assert not re.search(r"\n\s+flat_(load|store|atomic)", body), k
+    for k in ("kajo_render_strict_big", "kajo_render_strict_biglist"):
+        r = res[k]
+        assert r["Occupancy"] == 4 and r["VGPRs"] <= 128 and r["VGPRs Spill"] <= 16, (k, r)
+        # the grid walk's two loads through a pointer of either home (LDS or global; integrator.inc.hip gridWalk) are the only flat accesses
+        body = asm[asm.index(k + ":"):]
+        body = body[:body.index("s_endpgm")]
+        flat = re.findall(r"\n\s+(flat_\w+)", body)
+        assert sorted(flat) == ["flat_load_dwordx2", "flat_load_ushort"], (k, flat)

@@ -362,11 +362,21 @@ KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* 
     }
 }
 
+// GHOME: where the grid's cell lists live -- 1 in LDS, 2 in global memory (the STRICT large-scene kernel instances, which know: typed
+// loads, one walk; kernel_strict.hip), 0 decided at run time (the known-answer kernels; the FAST render kernels, which carry both typed walks)
+template <int GHOME>
 KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float aT, float iaT, float& tMax, int& best, float& bestT0)
 {
+    if (GHOME == 1) {
+        gridWalkIn(sc, lds, lds.gridCellStartLds, lds.gridItemsLds, O, d, aT, iaT, tMax, best, bestT0);
+        return;
+    }
+    if (GHOME == 2) {
+        gridWalkIn(sc, lds, sc.grid.cellStart, sc.grid.items, O, d, aT, iaT, tMax, best, bestT0);
+        return;
+    }
 #if KAJO_STRICT
-    // (one instance over a pointer of either home: the second instance costs the STRICT large-scene kernel 20 more spilled
-    // registers than its typed loads win back)
+    // (the known-answer kernels: one instance over a pointer of either home -- flat loads; a second instance costs 20 more spilled registers)
     gridWalkIn(sc, lds, sc.grid.inLds ? lds.gridCellStartLds : sc.grid.cellStart, sc.grid.inLds ? lds.gridItemsLds : sc.grid.items, O, d, aT, iaT, tMax,
                best, bestT0);
 #else
@@ -380,7 +390,7 @@ KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float 
 // hasRay: the lane has a ray to trace. Lanes without one (holding a vertex, done) go through the motions of the every-object walk
 // -- it is the same instructions for the whole wave either way -- but must NOT set out on a grid walk with whatever their ray
 // registers hold: a wave walks as long as its longest lane.
-template <bool GRID>
+template <bool GRID, int GHOME = 0>
 KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRay = true)
 {
     float tMax = __builtin_inff(); // Ray.cpp:10-13; minDistance = 0
@@ -450,7 +460,7 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
             return Hit{np + ns, aT, aT};
 #endif
         if (hasRay)
-            gridWalk(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
+            gridWalk<GHOME>(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
         return Hit{best, tMax, bestT0};
     }
 #if !KAJO_STRICT
@@ -1023,7 +1033,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
 // light's visibility lists (lightReached) instead of costing the lane a trip of its own through the grid: the light loop of a
 // vertex runs to its end in ONE trip, as Shader::sampleLights does (Shader.cpp:50-86), and every trip's walk carries camera and
 // extension rays only. Same draws, same tests, same sums in the same order: the buffer does not change by a bit.
-template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool LISTS = false, bool ONE_LIGHT = false>
+template <bool COLD_LDS, bool KAT, bool SPLIT = false, bool LISTS = false, bool ONE_LIGHT = false, int GHOME = 0>
 KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 {
     const DSceneView& sc = args.scene;
@@ -1309,7 +1319,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
         KAJO_STAMP(0); // camera-ray block
         // ---- one ray per lane through the whole scene ------------------------------------------
-        const Hit hit = trace<!COLD_LDS>(sc, lds, O, d, mode == MODE_EXTEND || mode == MODE_SHADOW);
+        const Hit hit = trace<!COLD_LDS, GHOME>(sc, lds, O, d, mode == MODE_EXTEND || mode == MODE_SHADOW);
         KAJO_STAMP(1); // traversal
         if (counting) {
             ctrTraversals += __builtin_popcountll(activeMask);
@@ -1934,17 +1944,34 @@ extern "C" __global__ void __launch_bounds__(1024, KAJO_WAVES_PER_SIMD) KAJO_KER
 }
 
 // hot records in LDS, cold ones in global memory (large scenes)
+#ifdef KAJO_KERNEL_NAME_BIG_LG
+// (instances per home of the grid's cell lists -- LDS: the _lg names, global memory: the plain ones -- see gridWalk)
+#define KAJO_GHOME_PLAIN 2
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KERNEL_NAME_BIG_LG(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<false, false, false, false, false, 1>(args, ldsRaw);
+}
+
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KERNEL_NAME_BIGLIST_LG(const RenderArgs args)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    renderBody<false, false, false, true, false, 1>(args, ldsRaw);
+}
+#else
+#define KAJO_GHOME_PLAIN 0
+#endif
 extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KERNEL_NAME_BIG(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    renderBody<false, false>(args, ldsRaw);
+    renderBody<false, false, false, false, false, KAJO_GHOME_PLAIN>(args, ldsRaw);
 }
 
 // large scenes with per-light visibility lists: shadow queries answered inside the light loop (renderBody LISTS)
 extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_KERNEL_NAME_BIGLIST(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-    renderBody<false, false, false, true>(args, ldsRaw);
+    renderBody<false, false, false, true, false, KAJO_GHOME_PLAIN>(args, ldsRaw);
 }
 
 // known-answer kernels (kajo_hip_kat_shade / kajo_hip_kat_trace): the SAME device functions, fed rays

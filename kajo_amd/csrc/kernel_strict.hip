@@ -12,6 +12,11 @@
 #endif
 #define KAJO_KERNEL_NAME_BIG kajo_render_strict_big
 #define KAJO_KERNEL_NAME_BIGLIST kajo_render_strict_biglist
+// Large scenes, STRICT: an instance per home of the grid's cell lists (LDS: _lg; global memory: the plain names), each with typed loads and
+// ONE walk -- a walk over a pointer of either home loads FLAT with a full wait behind every cell record, two walks in one kernel spill 20
+// registers more. 1000 spheres / 16 lights: 3.25 -> 3.31 G paths/s. (FAST carries both walks in one kernel and measures 0.7 % faster so.)
+#define KAJO_KERNEL_NAME_BIG_LG kajo_render_strict_big_lg
+#define KAJO_KERNEL_NAME_BIGLIST_LG kajo_render_strict_biglist_lg
 #define KAJO_KERNEL_NAME_SPLIT kajo_render_strict_split
 #define KAJO_KAT_SHADE_NAME kajo_kat_shade_strict
 #define KAJO_KAT_TRACE_NAME kajo_kat_trace_strict

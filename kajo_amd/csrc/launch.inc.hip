@@ -14,6 +14,12 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _launch)(const RenderArgs* args, int c
 #endif
     if (coldInLds)
         hipLaunchKernelGGL(KAJO_KERNEL_NAME, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
+#ifdef KAJO_KERNEL_NAME_BIG_LG
+    else if (args->scene.grid.enabled && args->scene.grid.inLds && args->scene.shadow.enabled)
+        hipLaunchKernelGGL(KAJO_KERNEL_NAME_BIGLIST_LG, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
+    else if (args->scene.grid.enabled && args->scene.grid.inLds)
+        hipLaunchKernelGGL(KAJO_KERNEL_NAME_BIG_LG, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
+#endif
     else if (args->scene.shadow.enabled)
         hipLaunchKernelGGL(KAJO_KERNEL_NAME_BIGLIST, dim3(grid), dim3(block), ldsBytes, static_cast<hipStream_t>(stream), *args);
     else
@@ -48,6 +54,12 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(int coldInLds, size_t ldsByt
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIG), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
         if (e == hipSuccess)
             e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIGLIST), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+#ifdef KAJO_KERNEL_NAME_BIG_LG
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIG_LG), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME_BIGLIST_LG), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
+#endif
     }
     if (e == hipSuccess)
         highWater[k] = ldsBytes;

@@ -35,15 +35,20 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _split_launch)(const RenderArgs* args,
 }
 
 // Dynamic LDS above the 64 KiB default needs an explicit opt-in on the function. The attribute is state of the
-// FUNCTION, shared by every handle of the process: it is only ever raised (a later, smaller scene must not lower the
-// limit under an earlier handle's launches).
+// FUNCTION ON A DEVICE, shared by every handle of the process on that device: it is only ever raised (a later, smaller
+// scene must not lower the limit under an earlier handle's launches), and remembered per device -- a process that drives
+// several GPUs (hip::Scheduler) sets it on each. Called with the handle's device current (kajo_hip_create).
 extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(int coldInLds, size_t ldsBytes)
 {
-    static size_t highWater[2] = {0, 0};
+    static size_t highWaterOfDevice[64][2] = {};
+    int device = 0;
+    hipError_t e = hipGetDevice(&device);
+    if (e != hipSuccess)
+        return (int)e;
+    size_t* highWater = highWaterOfDevice[device & 63];
     const int k = coldInLds ? 1 : 0;
     if (ldsBytes <= highWater[k])
         return (int)hipSuccess;
-    hipError_t e;
     if (coldInLds) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(KAJO_KERNEL_NAME), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsBytes);
 #ifdef KAJO_KERNEL_NAME_LIGHTS

@@ -67,6 +67,11 @@ extern "C" {
 #define KAJO_FLAG_NO_SPLIT 16u  /* small frames: do not let several waves share a pixel block and divide the passes */
 #define KAJO_FLAG_NO_SHADOW_LISTS 128u /* large scenes: shadow rays walk the uniform grid as extension rays do, instead of being answered
                                    from the lights' visibility lists inside the light loop (same results; for A/B runs and tests) */
+#define KAJO_FLAG_EXACT 512u  /* decision-exact numerics (round 5): the oracle's arithmetic (KAJO_FLAG_STRICT's) wherever a value can reach a
+                                   decision -- the closest-hit walk, hit points, normals, sampled directions, coins -- so every path meets the
+                                   oracle's objects, draws its random numbers and ends in its generator state; the fast forms where a value
+                                   only scales radiance (BSDF values and pdfs, the light pdf, MIS weights, throughput products). The buffer
+                                   differs from KAJO_FLAG_STRICT's in the last places of each path's radiance. Not with KAJO_FLAG_STRICT. */
 #define KAJO_FLAG_NO_ONE_LIGHT 256u /* small scenes with exactly one light, FAST numerics: run the kernel instance of any number of lights
                                    instead of the one that samples the BSDF in the light's visit (same results; for A/B runs and tests) */
 
@@ -171,7 +176,9 @@ int kajo_hip_kat_trace(kajo_hip_t h, int n, const float* origins, const float* d
                        float* position, float* normal, float* tangent, float* binormal);
 int kajo_hip_kat_shade(kajo_hip_t h, int n, const float* origins, const float* dirs, const uint64_t* states, float* rgb,
                        uint64_t* finalStates);
-/* include/kajo_strictmath.h evaluated on the device, element-wise: fn 0 sin, 1 cos, 2 asin, 3 acos, 4 pow(x, y). */
+/* include/kajo_strictmath.h evaluated on the device, element-wise: fn 0 sin, 1 cos, 2 asin, 3 acos, 4 pow(x, y); and the two IEEE
+   operations the STRICT / EXACT kernels form by hand (the reference's `/` and glm's sqrt, renderer/cpu/Raytracer.cpp:30-44):
+   fn 5 x / y, fn 6 sqrt(x). */
 int kajo_hip_kat_strictmath(kajo_hip_t h, int fn, int n, const float* x, const float* y, float* out);
 
 const char* kajo_hip_last_error(void);

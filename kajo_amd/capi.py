@@ -29,6 +29,7 @@ KAJO_FLAG_COOP = 32      # experiment library libkajo_hip_r02.so only
 KAJO_FLAG_DEFERRED = 64  # experiment library libkajo_hip_exp.so only
 KAJO_FLAG_NO_SHADOW_LISTS = 128
 KAJO_FLAG_NO_ONE_LIGHT = 256
+KAJO_FLAG_EXACT = 512  # decision-exact numerics: STRICT's decisions, FAST's radiance arithmetic
 
 # every symbol include/kajo_hip.h declares
 EXPORTS = [

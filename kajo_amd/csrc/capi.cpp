@@ -22,8 +22,12 @@
 #include "stage.h"
 #include "tuning.h"
 
-// launchers defined next to their kernels (kernel_fast.hip, kernel_strict.hip, aux_kernels.hip)
+// launchers defined next to their kernels (kernel_fast.hip, kernel_strict.hip, kernel_exact.hip, aux_kernels.hip)
 extern "C" {
+int kajo_render_exact_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
+int kajo_render_exact_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
+int kajo_render_exact_set_lds(int coldInLds, size_t lds);
+int kajo_kat_shade_exact_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_render_fast_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_strict_launch(const RenderArgs*, int coldInLds, unsigned grid, unsigned block, size_t lds, void* stream);
 int kajo_render_fast_split_launch(const RenderArgs*, unsigned grid, unsigned block, size_t lds, void* stream);
@@ -131,7 +135,34 @@ struct KajoHip
     double kernelMs = 0.0;
     uint64_t launches = 0;
 
-    bool strict() const { return params.flags & KAJO_FLAG_STRICT; }
+    // numerics build the handle runs (include/kajo_hip.h): 0 FAST, 1 STRICT, 2 EXACT
+    int numerics() const { return (params.flags & KAJO_FLAG_STRICT) ? 1 : ((params.flags & KAJO_FLAG_EXACT) ? 2 : 0); }
+    // the oracle's arithmetic in everything that decides (STRICT and EXACT): which walk, which hold policy, whose resolve
+    bool strict() const { return numerics() != 0; }
+    int launchRender(const RenderArgs* a, int home, unsigned grid, unsigned block, size_t lds) const
+    {
+        switch (numerics()) {
+        case 1: return kajo_render_strict_launch(a, home, grid, block, lds, stream);
+        case 2: return kajo_render_exact_launch(a, home, grid, block, lds, stream);
+        default: return kajo_render_fast_launch(a, home, grid, block, lds, stream);
+        }
+    }
+    int launchSplit(const RenderArgs* a, unsigned grid, unsigned block, size_t lds) const
+    {
+        switch (numerics()) {
+        case 1: return kajo_render_strict_split_launch(a, grid, block, lds, stream);
+        case 2: return kajo_render_exact_split_launch(a, grid, block, lds, stream);
+        default: return kajo_render_fast_split_launch(a, grid, block, lds, stream);
+        }
+    }
+    int setLds(size_t lds) const
+    {
+        switch (numerics()) {
+        case 1: return kajo_render_strict_set_lds(coldInLds, lds);
+        case 2: return kajo_render_exact_set_lds(coldInLds, lds);
+        default: return kajo_render_fast_set_lds(coldInLds, lds);
+        }
+    }
 };
 
 namespace
@@ -316,6 +347,8 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         p.tileCount = 1;
     if (p.samplesPerPass < 1 || p.samplesPerPass > 65535)
         return fail(KAJO_E_INVALID, "samplesPerPass must be in [1, 65535]");
+    if ((p.flags & KAJO_FLAG_STRICT) && (p.flags & KAJO_FLAG_EXACT))
+        return fail(KAJO_E_INVALID, "the strict and the exact flag name two different numerics builds: set one");
     if (p.flags & KAJO_FLAG_COOP)
         return fail(KAJO_E_INVALID, "KAJO_FLAG_COOP: the cooperative-traversal experiment is not built into this library (make -C kajo_amd/csrc experiments)");
     if (p.flags & KAJO_FLAG_DEFERRED)
@@ -521,8 +554,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     {
         const size_t ldsTotal = ((h->ldsBytes + 15) & ~(size_t)15) + (size_t)h->wavesPerBlock * h->perWaveBytes(true);
         if (ldsTotal > 48 * 1024) {
-            CREATE_TRY((hipError_t)(h->strict() ? kajo_render_strict_set_lds(h->coldInLds, ldsTotal)
-                                                : kajo_render_fast_set_lds(h->coldInLds, ldsTotal)));
+            CREATE_TRY((hipError_t)h->setLds(ldsTotal));
         }
     }
     CREATE_TRY(hipStreamSynchronize(h->stream));
@@ -661,8 +693,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             h->fillWaveLds(b, a.mailboxOffset + (size_t)now * a.n * a.n * 64 * 16, false); // behind the [pass][sample][pixel] table
             b.thrL = 1; // (short waves: holding a vertex only lengthens their tail -- configs[0] 18.9 against 16.5 G paths/s)
             const size_t ldsSplit = b.perWaveOffset + (size_t)waves * b.perWaveBytes;
-            le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * waves, ldsSplit, h->stream)
-                                          : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * waves, ldsSplit, h->stream));
+            le = (hipError_t)h->launchSplit(&b, (unsigned)pixelBlocks, 64 * waves, ldsSplit);
         } else if (split > 1) {
             RenderArgs b = a;
             b.blockOrder = nullptr; // one round or two: the launch order does not matter
@@ -670,13 +701,11 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             h->fillWaveLds(b, a.mailboxOffset + (size_t)now * 64 * 16, false); // behind the [pass][pixel] term table
             b.thrL = 1; // (as above: 1-3 % on frames below 720p)
             const size_t ldsSplit = b.perWaveOffset + (size_t)split * b.perWaveBytes;
-            le = (hipError_t)(h->strict() ? kajo_render_strict_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream)
-                                          : kajo_render_fast_split_launch(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit, h->stream));
+            le = (hipError_t)h->launchSplit(&b, (unsigned)pixelBlocks, 64 * split, ldsSplit);
         } else {
             // (coldInLds 2: the small-scene instance of any number of lights although the scene has one, KAJO_FLAG_NO_ONE_LIGHT)
             const int home = (h->coldInLds && (h->params.flags & KAJO_FLAG_NO_ONE_LIGHT)) ? 2 : h->coldInLds;
-            le = (hipError_t)(h->strict() ? kajo_render_strict_launch(&a, home, grid, block, ldsTotal, h->stream)
-                                          : kajo_render_fast_launch(&a, home, grid, block, ldsTotal, h->stream));
+            le = (hipError_t)h->launchRender(&a, home, grid, block, ldsTotal);
         }
         if (le != hipSuccess) {
             h->eventPool.push_back(e0);
@@ -969,8 +998,9 @@ int kajo_hip_kat_shade(kajo_hip_t h, int n, const float* origins, const float* d
     if (ldsKat > 64 * 1024)
         return fail(KAJO_E_INVALID, "known-answer entry points are limited to scenes whose hot records and wave areas fit 64 KiB of LDS");
     const unsigned grid = (unsigned)((n + 255) / 256);
-    hipError_t le = (hipError_t)(h->strict() ? kajo_kat_shade_strict_launch(&a, grid, ldsKat, h->stream)
-                                  : kajo_kat_shade_fast_launch(&a, grid, ldsKat, h->stream));
+    hipError_t le = (hipError_t)(h->numerics() == 1 ? kajo_kat_shade_strict_launch(&a, grid, ldsKat, h->stream)
+                                 : h->numerics() == 2 ? kajo_kat_shade_exact_launch(&a, grid, ldsKat, h->stream)
+                                                      : kajo_kat_shade_fast_launch(&a, grid, ldsKat, h->stream));
     if (le != hipSuccess)
         return failHip(le, "kat shade launch");
     std::vector<float> out4((size_t)n * 4);

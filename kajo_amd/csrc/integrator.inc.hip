@@ -1,11 +1,19 @@
 // integrator.inc.hip -- the per-pixel Monte-Carlo integrator as ONE wave64 megakernel.
 //
-// Included twice: kernel_fast.hip (KAJO_STRICT 0, compiled with FMA contraction and the
-// gfx950 hardware transcendentals) and kernel_strict.hip (KAJO_STRICT 1, compiled
+// Included three times: kernel_fast.hip (KAJO_STRICT 0, compiled with FMA contraction and the
+// gfx950 hardware transcendentals), kernel_strict.hip (KAJO_STRICT 1, compiled
 // -ffp-contract=off, include/kajo_strictmath.h for the five libm functions, IEEE divide and
-// sqrt, binary64 exactly where the reference's expressions promote through M_PI / M_1_PI).
+// sqrt, binary64 exactly where the reference's expressions promote through M_PI / M_1_PI) and
+// kernel_exact.hip (KAJO_STRICT 1 + KAJO_EXACT 1, compiled -ffp-contract=off as well).
 // STRICT exists to prove that the kernel takes, path for path, the decisions of the CPU
-// integrator (it is compared bit for bit with the oracle); FAST is the product path.
+// integrator (it is compared bit for bit with the oracle); FAST is the fastest path.
+// EXACT ("decision-exact", round 5) is STRICT wherever a value can reach a DECISION -- the closest-hit
+// walk, hit point, normal, reflection vector, every sampled direction, every coin, the generator -- so each
+// path meets the oracle's objects, draws the oracle's random numbers and ends in the oracle's generator state;
+// and FAST wherever a value only SCALES what the path carries: BSDF values and pdfs toward a given direction
+// (BSDF.cpp:30-39,62-74,87-91), the light's pdf (Light.cpp:48-62), the MIS weight and the throughput /
+// contribution products (Shader.cpp:74-83,203-212). Its radiance differs from the oracle's in the last places
+// of each path's products and in nothing else: KAJO_RSTRICT below marks the forks that are radiance only.
 //
 // What it replaces (reference file:line):
 //   camera ray generation + sample loop     renderer/cpu/Renderer.cpp:38-72
@@ -32,6 +40,14 @@
 #include "device_scene.h"
 #include "kajo_stream.h"
 #include "render_args.h"
+#ifndef KAJO_EXACT
+#define KAJO_EXACT 0
+#endif
+#if KAJO_EXACT && !KAJO_STRICT
+#error "KAJO_EXACT is a variant of the STRICT build"
+#endif
+// the oracle's arithmetic for values that only scale radiance, too (STRICT proper)
+#define KAJO_RSTRICT (KAJO_STRICT && !KAJO_EXACT)
 #if KAJO_STRICT
 #include "kajo_strictmath.h"
 #endif
@@ -60,9 +76,52 @@ KDEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 
 // ---- numerics policy ------------------------------------------------------------------
 #if KAJO_STRICT
+#ifndef KAJO_IEEE_BY_COMPILER
+#define KAJO_IEEE_BY_COMPILER 0 // 1: `a / b` and __builtin_sqrtf as hipcc lowers them (the A/B baseline of the two functions below)
+#endif
+#if KAJO_IEEE_BY_COMPILER
 KDEV float kdiv(float a, float b) { return a / b; }
 KDEV float ksqrt(float a) { return __builtin_sqrtf(a); }
-KDEV float krcp(float a) { return 1.0f / a; }
+#else
+// The correctly rounded quotient and square root, as hipcc's own lowering computes them, WITHOUT its range scaling.
+// hipcc: v_div_scale x2 (pre-scale by 2^+-64 when the denominator is subnormal or beyond 2^126, the exponents are 96 or more apart,
+// the quotient would be subnormal, or the numerator is below 2^-103), v_rcp, one Newton step on the reciprocal, quotient, two residual
+// corrections (the last one v_div_fmas, which undoes the scaling), v_div_fixup (zeros, infinities, NaNs): 11 instructions, four of
+// them in the half-rate classes. Below: the same v_rcp, the same six FMAs / multiply on the same operands, the same v_div_fixup -- 9
+// instructions, one half-rate -- so every operand pair that v_div_scale leaves alone gets hipcc's bits, i.e. the IEEE quotient the
+// oracle's x86 division returns. The walk's operands -- plane offsets over direction components no smaller than FLT_EPSILON
+// (Raytracer.cpp:82-85; the quotient of a smaller one is not used), roots q / a and c / q (Raytracer.cpp:36-44), reciprocal lengths --
+// are zero or sit dozens of binades inside that range for any scene whose non-zero coordinates lie in 2^-40 .. 2^40: a difference of
+// binary32 values is zero or at least 2^-24 of the smaller one. tests/test_hip_exact.py pins both functions against IEEE on 2^22
+// operand pairs over 2^-47 .. 2^47 plus the special values, and every STRICT = oracle frame test pins them in the walk.
+KDEV float kdiv(float a, float b)
+{
+    float y = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    float q = a * y;
+    float r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    return __builtin_amdgcn_div_fixupf(q, b, a);
+}
+// hipcc: scale arguments below 2^-96 by 2^32, v_sqrt (1 ulp), the two neighbours of its result by integer +-1, the exact residuals
+// x - s * neighbour (one FMA each) pick the correctly rounded one, unscale, and a v_cmp_class patch for 0 / inf: 16 instructions, nine
+// half-rate. Below: the middle part alone, 9 instructions. Zeros, infinities, NaNs and negative arguments fall through the two
+// selections unchanged (their residuals are NaN or zero: no comparison holds), so only arguments in (0, 2^-96) are outside its domain:
+// a discriminant, squared length or variate is zero or above 2^-64 under the range stated above.
+KDEV float ksqrt(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    const float sd = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) - 1u), su = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, s) + 1u);
+    const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    s = 0.0f >= rd ? sd : s;
+    s = 0.0f < ru ? su : s;
+    return s;
+}
+#endif
+KDEV float krcp(float a) { return kdiv(1.0f, a); }
 KDEV float kpow(float x, float y) { return kajo_powf(x, y); }
 #else
 // FAST: the hardware's 1-ulp reciprocal, square root and reciprocal square root (profiles/r01_hwmath_accuracy.txt; swapping in
@@ -80,10 +139,17 @@ KDEV float kpow(float x, float y)
 }
 #endif
 // the Phong lobe: its exponent is never zero (a zero exponent selects the ideal reflector, Shader.cpp:155-158)
-#if KAJO_STRICT
+// (value and pdf toward a GIVEN direction: radiance only)
+#if KAJO_RSTRICT
 KDEV float kpowPhong(float x, float y) { return kajo_powf(x, y); }
 #else
 KDEV float kpowPhong(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+#endif
+// reciprocal of a value that only scales radiance (a pdf, a pdf sum, a clamped cosine under a colour)
+#if KAJO_RSTRICT
+KDEV float rrcp(float a) { return kdiv(1.0f, a); }
+#else
+KDEV float rrcp(float a) { return __builtin_amdgcn_rcpf(a); }
 #endif
 
 // max(0, x) for an x that cannot exceed 1 (cosines of unit vectors, 1 - u, 1 - x^2): FAST folds it into the
@@ -98,7 +164,7 @@ KDEV F3 normalize(F3 a)
 {
     float sqr = a.x * a.x + a.y * a.y + a.z * a.z;
 #if KAJO_STRICT
-    return a * (1.0f / __builtin_sqrtf(sqr)); // glm: x * inversesqrt(dot), inversesqrt = 1 / sqrt
+    return a * kdiv(1.0f, ksqrt(sqr)); // glm: x * inversesqrt(dot), inversesqrt = 1 / sqrt
 #else
     return a * krsq(sqr);
 #endif
@@ -111,6 +177,8 @@ const float kEps = 0.001f;              // g_surfaceEpsilon, Shader.cpp:23
 const float kFltEpsilon = 1.1920929e-7f; // std::numeric_limits<float>::epsilon()
 #if KAJO_STRICT
 const double kPi = 3.14159265358979323846;
+#endif
+#if KAJO_RSTRICT
 const double kInvPi = 0.31830988618379067154;
 #else
 const float kInvPiF = 0.31830988618379067154f;
@@ -673,7 +741,7 @@ KDEV F3 hitNormal(const DSceneView& sc, const LdsScene& lds, const Hit& h, F3 O,
 KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
 {
     if (kind == 0) { // BSDF.cpp:30-33
-#if KAJO_STRICT
+#if KAJO_RSTRICT
         return color * (float)kInvPi;
 #else
         return color * kInvPiF;
@@ -681,22 +749,26 @@ KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
     }
     if (kind == 1) { // BSDF.cpp:62-67
         float cosA = kmax0(dot(R, dir));
-#if KAJO_STRICT
+#if KAJO_RSTRICT
         float s = (float)((double)(exponent + 1) / (2 * kPi));
 #else
         float s = (exponent + 1) * kInv2PiF;
 #endif
-        return (s * color) * kpow(cosA, exponent);
+        return (s * color) * kpowPhong(cosA, exponent);
     }
     float cosA = kmax0(dot(dir, N)); // BSDF.cpp:87-91
+#if KAJO_RSTRICT
     return f3(kdiv(color.x, cosA), kdiv(color.y, cosA), kdiv(color.z, cosA));
+#else
+    return color * rrcp(cosA);
+#endif
 }
 
 KDEV float bsdfProbability(int kind, float exponent, F3 R, F3 N, F3 dir)
 {
     if (kind == 0) { // BSDF.cpp:35-39
         float cosT = dot(dir, N);
-#if KAJO_STRICT
+#if KAJO_RSTRICT
         return (float)(kInvPi * (double)cosT);
 #else
         return kInvPiF * cosT;
@@ -704,10 +776,10 @@ KDEV float bsdfProbability(int kind, float exponent, F3 R, F3 N, F3 dir)
     }
     if (kind == 1) { // BSDF.cpp:69-74
         float cosA = kmax0(dot(R, dir));
-#if KAJO_STRICT
-        return (float)((double)(exponent + 1) / (2 * kPi) * (double)kpow(cosA, exponent));
+#if KAJO_RSTRICT
+        return (float)((double)(exponent + 1) / (2 * kPi) * (double)kpowPhong(cosA, exponent));
 #else
-        return (exponent + 1) * kInv2PiF * kpow(cosA, exponent);
+        return (exponent + 1) * kInv2PiF * kpowPhong(cosA, exponent);
 #endif
     }
     return 0.0f; // BSDF.cpp:93-96
@@ -719,7 +791,7 @@ KDEV F3 bsdfEvaluateWithPdf(int kind, F3 color, float exponent, F3 R, F3 N, F3 d
 {
     if (kind == 1) { // BSDF.cpp:62-74
         const float pw = kpowPhong(kmax0(dot(R, dir)), exponent);
-#if KAJO_STRICT
+#if KAJO_RSTRICT
         pdf = (float)((double)(exponent + 1) / (2 * kPi) * (double)pw);
         const float s = (float)((double)(exponent + 1) / (2 * kPi));
 #else
@@ -759,8 +831,12 @@ KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 b
         kajo_sincosf(phi, &sphi, &cphi);
         float x = r * cphi;
         float y = r * sphi;
-        float z = __builtin_sqrtf(fmaxf(0.0f, 1.0f - u));
+        float z = ksqrt(fmaxf(0.0f, 1.0f - u));
+#if KAJO_RSTRICT
         pdf = (float)((double)z * kInvPi);
+#else
+        pdf = z * kInvPiF; // (zero exactly when z is: the path ends on the same draw)
+#endif
 #else
         float x = r * __builtin_amdgcn_cosf(v); // v_cos_f32 takes revolutions: cos(2 pi v)
         float y = r * __builtin_amdgcn_sinf(v);
@@ -772,13 +848,28 @@ KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 b
     }
     F3 s;
 #if KAJO_STRICT
-    float a = kajo_acosf(kajo_powf(u, 1.0f / (exponent + 1)));
+    float a = kajo_acosf(kajo_powf(u, kdiv(1.0f, exponent + 1)));
     float phi = (float)(2 * kPi * (double)v);
     float sa, ca, sphi, cphi;
     kajo_sincosf(a, &sa, &ca);
     kajo_sincosf(phi, &sphi, &cphi);
     s = f3(sa * cphi, sa * sphi, ca);
+#if KAJO_RSTRICT
     pdf = (float)((double)(exponent + 1) / (2 * kPi) * (double)kajo_powf(ca, exponent));
+#else
+    {
+        // EXACT: the direction above is the oracle's; its pdf and the lobe's value toward it are the FAST forms over the oracle's
+        // cosine (cos of the angle to R of the generated direction IS the sampled cosine). Whether the pdf is ZERO is a decision
+        // (Shader.cpp:198-199: the path ends): the power can only vanish when the variate is 0 exactly -- the cosine is
+        // u^(1/(e+1)) >= 2^-32 otherwise and its e-th power at least 2^-32 -- and that draw (one in 2^32) takes the oracle's power.
+        float pw = kpowPhong(ca, exponent);
+        if (u == 0.0f)
+            pw = kajo_powf(ca, exponent);
+        const float sc = (exponent + 1) * kInv2PiF;
+        pdf = sc * pw;
+        value = (sc * color) * pw;
+    }
+#endif
 #else
     // cos(acos(c)) = c and sin(acos(c)) = sqrt(1 - c^2): no inverse trigonometry needed
     const float lca = __builtin_amdgcn_logf(u) * krcp(exponent + 1); // log2 of the sampled cosine
@@ -801,7 +892,7 @@ KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 b
 #endif
     const F3 nd = f3(uu.x * s.x + vv.x * s.y + R.x * s.z, uu.y * s.x + vv.y * s.y + R.y * s.z,
                      uu.z * s.x + vv.z * s.y + R.z * s.z);
-#if KAJO_STRICT
+#if KAJO_RSTRICT
     value = bsdfEvaluate(1, color, exponent, R, N, nd);
 #endif
     return nd;
@@ -829,7 +920,7 @@ KDEV float solidAngle(F3 centre, float radius, F3 P)
 #if KAJO_STRICT
     if (dist < radius)
         return (float)(4 * kPi);
-    return (float)(2 * kPi * (double)(1 - kajo_cosf(kajo_asinf(radius / dist))));
+    return (float)(2 * kPi * (double)(1 - kajo_cosf(kajo_asinf(kdiv(radius, dist)))));
 #else
     // 1 - cos(asin x) = x^2 / (1 + sqrt(1 - x^2)): same value without the cancellation
     float x = radius * krcp(dist);
@@ -839,7 +930,7 @@ KDEV float solidAngle(F3 centre, float radius, F3 P)
 #endif
 }
 
-#if !KAJO_STRICT
+#if !KAJO_RSTRICT
 // 1 / solidAngle without forming the angle: with x = r / dist,
 // 1 / (2 pi (1 - cos asin x)) = (1 + sqrt(1 - x^2)) / (2 pi x^2) = (1 + sqrt(1 - r^2/d^2)) d^2 / (2 pi r^2)
 KDEV float lightPdf(const DSphereCold& lc, F3 P)
@@ -847,8 +938,8 @@ KDEV float lightPdf(const DSphereCold& lc, F3 P)
     F3 v = f3(lc.cx - P.x, lc.cy - P.y, lc.cz - P.z);
     float d2 = dot(v, v);
     float r2 = lc.radius * lc.radius;
-    float x2 = r2 * krcp(d2);
-    float p = (1.0f + ksqrt(kmax0(1.0f - x2))) * d2 * lc.invTwoPiR2;
+    float x2 = r2 * rrcp(d2);
+    float p = (1.0f + __builtin_amdgcn_sqrtf(kmax0(1.0f - x2))) * d2 * lc.invTwoPiR2;
     return d2 < r2 ? 0.07957747154594767f : p; // inside the light: 1 / (4 pi)
 }
 #endif
@@ -861,9 +952,9 @@ KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
     float ang = (float)(2 * kPi * (double)s2);
     float sang, cang;
     kajo_sincosf(ang, &sang, &cang);
-    float x = radius * __builtin_sqrtf(s1) * cang;
-    float y = radius * __builtin_sqrtf(s1) * sang;
-    float z = __builtin_sqrtf(radius * radius - x * x - y * y) * kajo_sinf((float)(kPi * (double)(s3 - .5f)));
+    float x = radius * ksqrt(s1) * cang;
+    float y = radius * ksqrt(s1) * sang;
+    float z = ksqrt(radius * radius - x * x - y * y) * kajo_sinf((float)(kPi * (double)(s3 - .5f)));
 #else
     float rs = radius * ksqrt(s1);
     float x = rs * __builtin_amdgcn_cosf(s2);
@@ -871,7 +962,7 @@ KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
     float z = ksqrt(radius * radius - x * x - y * y) * __builtin_amdgcn_sinf((s3 - .5f) * .5f);
 #endif
     F3 dir = normalize(centre + f3(x, y, z) - P);
-#if KAJO_STRICT
+#if KAJO_RSTRICT
     pdf = krcp(solidAngle(centre, radius, P));
 #endif
     return dir;
@@ -1128,7 +1219,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // used instead of carried across the traversal. FAST also sums the vertex's emission and its light samples in one vector.)
     F3 vP = origin, vN = d, vR = d, vE = L;
     int vId = 0, vKind = 0, lightK = 0;
-#if KAJO_STRICT
+#if KAJO_RSTRICT
     F3 vLd = L;
     float vS = 0.0f; // of the vertex the extension ray left: the MIS correction re-forms the weight with it
 #endif
@@ -1136,8 +1227,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // extension ray sampled from the BSDF: weight pieces that wait for the light pdf of the hit
     bool pendBsdf = false;
     // (STRICT re-forms the weight from its pieces, in the reference's order; FAST scales the eager throughput by
-    // p / (pL + p) -- the same value -- and carries only p: seven registers less across the traversal)
-#if KAJO_STRICT
+    // p / (pL + p) -- the same value -- and carries only p: seven registers less across the traversal; so does EXACT)
+#if KAJO_RSTRICT
     F3 pendF = L, pendT = L;
     float pendCos = 0.0f;
 #endif
@@ -1188,8 +1279,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #ifdef KAJO_PROFILE
     stampLast = __builtin_amdgcn_s_memtime();
 #endif
-#if !KAJO_STRICT
-    const float invS = krcp(args.S);
+#if !KAJO_RSTRICT
+    const float invS = rrcp(args.S);
 #endif
     uint32_t trips = 0;
     int heldTrips = 0; // (wave-uniform) consecutive trips in which some lane wanted the light / BSDF blocks and they did not run
@@ -1217,8 +1308,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
         if (!KAT && mode == MODE_NEW) {
             if (sampleY == endY && sampleX == endX) { // pass complete: Renderer.cpp:70-71
-#if KAJO_STRICT
-                const F3 term = f3(radiance.x / args.S, radiance.y / args.S, radiance.z / args.S);
+#if KAJO_RSTRICT
+                const F3 term = f3(kdiv(radiance.x, args.S), kdiv(radiance.y, args.S), kdiv(radiance.z, args.S));
 #else
                 const F3 term = radiance * invS;
 #endif
@@ -1346,22 +1437,20 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // (Shader.cpp:121,212): its throughput is never used again, so the MIS correction is skipped. STRICT
                 // keeps it when the throughput is not finite: NaN * 0 must stay NaN.)
 #if KAJO_STRICT
+                // (EXACT keeps the test: its throughput is the oracle's to the last places, so it is finite where the oracle's is)
                 const bool weightMatters = m0.x != 0.0f || !(__builtin_fabsf(T.x) < __builtin_inff() && __builtin_fabsf(T.y) < __builtin_inff() && __builtin_fabsf(T.z) < __builtin_inff());
 #else
                 const bool weightMatters = m0.x != 0.0f;
 #endif
                 if (hit.id > np && hit.id != vId && (m1flags & KAJO_MAT_IS_LIGHT) && weightMatters) {
                     const DSphereCold& lc = lds.sphereCold[hit.id - 1 - np];
-#if KAJO_STRICT
+#if KAJO_RSTRICT
                     const float pL = krcp(solidAngle(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP));
-#else
-                    const float pL = lightPdf(lc, vP);
-#endif
-#if KAJO_STRICT
                     const F3 wb = (krcp(pL + pendP) * pendF) * pendCos;
                     T = pendT * (vS * wb);
 #else
-                    T = T * (pendP * krcp(pL + pendP));
+                    const float pL = lightPdf(lc, vP);
+                    T = T * (pendP * rrcp(pL + pendP));
 #endif
                 }
                 collectEmission = false; // SampleNonEmissiveObjects
@@ -1399,7 +1488,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         F3 nd = transmissionDirection(view, vN, m2.w);
                         float cosA = __builtin_fabsf(dot(nd, vN));
                         F3 spec = f3(m2.x, m2.y, m2.z);
+#if KAJO_RSTRICT
                         F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
+#else
+                        F3 f = spec * rrcp(cosA);
+#endif
                         F3 w = (m4.z * f) * __builtin_fabsf(dot(vN, nd)); // sTransparent = 1/pc * 1/pt, Shader.cpp:146-147
                         L = L + T * (w * vE);
                         T = T * w;
@@ -1412,7 +1505,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         const bool diffuse = flipCoin(rng, m0.z, pd); // Shader.cpp:153-154
                         vKind = diffuse ? 0 : ((m1flags & KAJO_MAT_HAS_EXPONENT) ? 1 : 2);
                         vR = reflect(view, vN);
-#if KAJO_STRICT
+#if KAJO_RSTRICT
                         vLd = f3(0.0f, 0.0f, 0.0f);
 #endif
                         lightK = 0;
@@ -1425,14 +1518,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             constexpr bool pre = PRESAMPLE; // the extension ray was sampled together with the light (every shadow ray of the one-light instance)
             const int lk = pre ? 0 : lightK;
             if (hit.id == np + 1 + lds.light[lk]) {
-#if KAJO_STRICT
+#if KAJO_RSTRICT
                 vLd = vLd + pendContrib;
 #else
                 vE = vE + pendContrib;
 #endif
             }
             if (pre) {
-#if KAJO_STRICT
+#if KAJO_RSTRICT
                 // ... and waits in the register of the vertex's normal; the weight is formed here from its pieces, which wait for
                 // the next hit's MIS correction anyway (the expressions of the BSDF sampling block, in its order)
                 L = L + T * (vS * (vE + vLd));
@@ -1550,7 +1643,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         const DSphereCold& lc = lds.lightCold[k];
                         float pl;
                         d = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
-#if !KAJO_STRICT
+#if !KAJO_RSTRICT
                         pl = lightPdf(lc, vP);
 #endif
                         float pb;
@@ -1559,7 +1652,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         O = vP + d * kEps;
                         if (!(pl == 0.0f || pb == 0.0f || (cosL == 0.0f && KAJO_IS_A_NUMBER(pb)))) { // (such a sample adds nothing whatever its shadow ray finds; see the loop further down)
                             const DFloat4 le = lds.lightEmission[k];
-                            pendContrib = ((krcp(pb + pl) * fl) * cosL) * f3(le.x, le.y, le.z);
+                            pendContrib = ((rrcp(pb + pl) * fl) * cosL) * f3(le.x, le.y, le.z);
                             if (counting)
                                 ctrShadow += 1;
                             hasQ = lightReachedHead(sc, lds, k, si, O, d, keyL);
@@ -1647,7 +1740,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     __builtin_amdgcn_wave_barrier();
                     KAJO_STAMP(7); // (lists walked)
                     if (hasQ && !blocked && helpFlag[lane] == 0u) { // Shader.cpp:72-80: the closest hit is the light
-#if KAJO_STRICT
+#if KAJO_RSTRICT
                         vLd = vLd + pendContrib;
 #else
                         // (the product above stays a rounded value of its own, as in the kernels where it waits a trip for its
@@ -1710,7 +1803,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 // written straight into the ray: a discarded sample leaves d and O to the next light or to the BSDF sample
                 d = lightGenerate(f3(lc.cx, lc.cy, lc.cz), lc.radius, vP, rng, pl);
                 const F3 l = d;
-#if !KAJO_STRICT
+#if !KAJO_RSTRICT
                 pl = lightPdf(lc, vP);
 #endif
                 // The reference traces first and asks the BSDF afterwards; a zero BSDF pdf (always for
@@ -1735,7 +1828,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
                 const DFloat4 le = lds.lightEmission[lightK];
                 const F3 Le = f3(le.x, le.y, le.z);
-                pendContrib = ((krcp(pb + pl) * fl) * cosL) * Le;
+                pendContrib = ((rrcp(pb + pl) * fl) * cosL) * Le;
 #if KAJO_INLINE_SHADOW
                 if (!LISTS && COLD_LDS && !KAT && !SPLIT && !PRESAMPLE) {
                     // Small scenes, STRICT build: the shadow ray walks the scene right here (the closest-hit walk itself, so the
@@ -1747,7 +1840,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         ctrShadow += 1;
                     const Hit sh = trace<false>(sc, lds, O, l);
                     if (sh.id == np + 1 + si) {
-#if KAJO_STRICT
+#if KAJO_RSTRICT
                         vLd = vLd + pendContrib;
 #else
                         asm volatile("" : "+v"(pendContrib.x), "+v"(pendContrib.y), "+v"(pendContrib.z));
@@ -1785,7 +1878,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
                 float p;
                 F3 fd;
-#if KAJO_STRICT
+#if KAJO_RSTRICT
                 const F3 dB = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
                 vS = vSl;
                 // The next segment's state is written unconditionally: a path that ends here (p == 0) re-initialises
@@ -1810,7 +1903,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
 #else
                 const F3 dB = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
-                const F3 w = vSl * ((krcp(p) * fd) * kmax0(dot(vN, dB)));
+                const F3 w = vSl * ((rrcp(p) * fd) * kmax0(dot(vN, dB)));
                 pendP = p;
                 pendBsdf = true;
                 depth++;
@@ -1858,8 +1951,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         const DFloat4 t = termTable[(p * n * n + k) * 64 + lane];
                         sum = sum + f3(t.x, t.y, t.z);
                     }
-#if KAJO_STRICT
-                    total = total + f3(sum.x / args.S, sum.y / args.S, sum.z / args.S);
+#if KAJO_RSTRICT
+                    total = total + f3(kdiv(sum.x, args.S), kdiv(sum.y, args.S), kdiv(sum.z, args.S));
 #else
                     total = total + sum * invS;
 #endif
@@ -1981,6 +2074,7 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_BIG) KAJO_
     renderBody<false, true>(args, ldsRaw);
 }
 
+#ifdef KAJO_KAT_TRACE_NAME // (the EXACT build's walk IS the STRICT build's: it has no instance of its own)
 extern "C" __global__ void __launch_bounds__(256) KAJO_KAT_TRACE_NAME(const KatTraceArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
@@ -2013,9 +2107,11 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_KAT_TRACE_NAME(const KatT
         o[3 + 3 * k] = v[k].z;
     }
 }
+#endif
 
 // ---- resolve (Renderer.cpp:73-75 + Image::linearToSRGB / colorToRGBA8, Image.cpp:14-27) ----------
 // frame: W*H float4 sums over passes; dst: ARGB8, row 0 = top.
+#ifdef KAJO_RESOLVE_NAME // (the EXACT build resolves with the STRICT build's kernels)
 extern "C" __global__ void __launch_bounds__(256) KAJO_RESOLVE_NAME(const float4* frame, int count, float passes, uint32_t* dst)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2057,3 +2153,4 @@ extern "C" __global__ void __launch_bounds__(256) KAJO_RESOLVE_TILES_NAME(const 
     const int al = (int)(1.f * 255.f + .5f);
     dst[(size_t)y * map.W + x] = ((uint32_t)al << 24) | ((uint32_t)out[0] << 16) | ((uint32_t)out[1] << 8) | (uint32_t)out[2];
 }
+#endif

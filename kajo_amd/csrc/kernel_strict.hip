@@ -27,7 +27,7 @@
 
 // include/kajo_strictmath.h element-wise on the device (kajo_hip_kat_strictmath): the claim that these
 // functions give identical bits on x86-64 and gfx950 is checked directly.
-// fn: 0 sin, 1 cos, 2 asin, 3 acos, 4 pow(x, y)
+// fn: 0 sin, 1 cos, 2 asin, 3 acos, 4 pow(x, y); 5 x / y and 6 sqrt(x) as the STRICT and EXACT kernels form them (integrator.inc.hip kdiv, ksqrt)
 extern "C" __global__ void __launch_bounds__(256) kajo_kat_math(int fn, int n, const float* x, const float* y, float* out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -39,6 +39,8 @@ extern "C" __global__ void __launch_bounds__(256) kajo_kat_math(int fn, int n, c
     case 1: r = kajo_cosf(x[i]); break;
     case 2: r = kajo_asinf(x[i]); break;
     case 3: r = kajo_acosf(x[i]); break;
+    case 5: r = kdiv(x[i], y[i]); break;
+    case 6: r = ksqrt(x[i]); break;
     default: r = kajo_powf(x[i], y[i]); break;
     }
     out[i] = r;

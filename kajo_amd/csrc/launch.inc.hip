@@ -71,6 +71,7 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(int coldInLds, size_t ldsByt
     return (int)e;
 }
 
+#ifdef KAJO_RESOLVE_NAME
 extern "C" int KAJO_CAT(KAJO_RESOLVE_NAME, _launch)(const void* frame, int count, float passes, void* dst, void* stream)
 {
     const unsigned block = 256, grid = (unsigned)((count + 255) / 256);
@@ -87,14 +88,18 @@ extern "C" int KAJO_CAT(KAJO_RESOLVE_TILES_NAME, _launch)(const void* gathered, 
     return (int)hipGetLastError();
 }
 
+#endif
+
 extern "C" int KAJO_CAT(KAJO_KAT_SHADE_NAME, _launch)(const RenderArgs* args, unsigned grid, size_t ldsBytes, void* stream)
 {
     hipLaunchKernelGGL(KAJO_KAT_SHADE_NAME, dim3(grid), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), *args);
     return (int)hipGetLastError();
 }
 
+#ifdef KAJO_KAT_TRACE_NAME
 extern "C" int KAJO_CAT(KAJO_KAT_TRACE_NAME, _launch)(const KatTraceArgs* args, unsigned grid, size_t ldsBytes, void* stream)
 {
     hipLaunchKernelGGL(KAJO_KAT_TRACE_NAME, dim3(grid), dim3(256), ldsBytes, static_cast<hipStream_t>(stream), *args);
     return (int)hipGetLastError();
 }
+#endif

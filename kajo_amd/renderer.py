@@ -16,7 +16,7 @@ from .scene import Scene
 
 class HipRenderer:
     def __init__(self, scene: Scene, width: int, height: int, spp: int = 32, depth_limit: int = 8,
-                 seed: int = 0o715517, strict: bool = False, counters: bool = False, device: int = 0,
+                 seed: int = 0o715517, strict: bool = False, exact: bool = False, counters: bool = False, device: int = 0,
                  tile=(64, 16), tile_index: int = 0, tile_count: int = 1, passes_per_launch: int = 0, flags: int = 0):
         L = capi.lib()
         self._L = L
@@ -28,7 +28,7 @@ class HipRenderer:
         p.samplesPerPass = spp
         p.depthLimit = depth_limit
         p.seed = seed
-        p.flags = (capi.KAJO_FLAG_STRICT if strict else 0) | (capi.KAJO_FLAG_COUNTERS if counters else 0) | int(flags)
+        p.flags = (capi.KAJO_FLAG_STRICT if strict else 0) | (capi.KAJO_FLAG_EXACT if exact else 0) | (capi.KAJO_FLAG_COUNTERS if counters else 0) | int(flags)
         p.device = device
         p.tileW, p.tileH = tile
         p.tileIndex, p.tileCount = tile_index, tile_count

@@ -57,8 +57,21 @@ KSM_FN double ksm_fma_coeff(double a, double b, double c)
     return r;
 }
 #define KSM_FMA(a, b, c) ksm_fma_coeff((a), (b), (c))
+/* The LEADING coefficient of a Horner chain is a vector operand (v_fma_f64 takes one scalar source). Left to itself the compiler
+   keeps it in a VGPR pair across the whole render loop -- a loop invariant -- and, in a loop short of registers, spills it; made
+   here from two literals where it is used (two v_mov_b32), it occupies nothing in between. */
+KSM_FN double ksm_lead_coeff(uint32_t lo, uint32_t hi)
+{
+    __asm__ volatile("" : "+v"(lo), "+v"(hi));
+    const uint64_t u = ((uint64_t)hi << 32) | lo;
+    double d;
+    __builtin_memcpy(&d, &u, 8);
+    return d;
+}
+#define KSM_LEAD(lo, hi, value) ksm_lead_coeff((lo), (hi))
 #else
 #define KSM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#define KSM_LEAD(lo, hi, value) (value)
 #endif
 
 KSM_FN uint64_t ksm_bits(double d)
@@ -259,7 +272,7 @@ KSM_FN float kajo_powf(float xf, float yf)
     m = big ? m * 0.5 : m;
     e += big;
     const double f = m - 1.0;
-    double p = -0x1.8e19bc29da973p-5;
+    double p = KSM_LEAD(0xc29da973u, 0xbfa8e19bu, -0x1.8e19bc29da973p-5);
     p = KSM_FMA(p, f, 0x1.736e0e73ee60bp-4);
     p = KSM_FMA(p, f, -0x1.79daf10d6f80dp-4);
     p = KSM_FMA(p, f, 0x1.724867257e45ep-4);
@@ -279,7 +292,7 @@ KSM_FN float kajo_powf(float xf, float yf)
     t = t < -1100.0 ? -1100.0 : t; /* a NaN passes through */
     const double n = __builtin_floor(t + 0.5);
     const double r = t - n;
-    double q = 0x1.00a581594758ep-16;
+    double q = KSM_LEAD(0x1594758eu, 0x3ef00a58u, 0x1.00a581594758ep-16);
     q = KSM_FMA(q, r, 0x1.443fffc90db59p-13);
     q = KSM_FMA(q, r, 0x1.5d879ead06a82p-10);
     q = KSM_FMA(q, r, 0x1.3b2a1b7152befp-7);

@@ -863,8 +863,10 @@ KDEV F3 bsdfGenerate(int kind, F3 color, float exponent, F3 R, F3 N, F3 tg, F3 b
         // (Shader.cpp:198-199: the path ends): the power can only vanish when the variate is 0 exactly -- the cosine is
         // u^(1/(e+1)) >= 2^-32 otherwise and its e-th power at least 2^-32 -- and that draw (one in 2^32) takes the oracle's power.
         float pw = kpowPhong(ca, exponent);
+#ifndef KAJO_X_NOPOWFALLBACK
         if (u == 0.0f)
             pw = kajo_powf(ca, exponent);
+#endif
         const float sc = (exponent + 1) * kInv2PiF;
         pdf = sc * pw;
         value = (sc * color) * pw;
@@ -1234,7 +1236,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #endif
     float pendP = 0.0f;
 
-    unsigned long long ctrTraversals = 0, ctrVertices = 0, ctrSlots = 0, ctrShadow = 0;
+    unsigned long long ctrTraversals = 0, ctrSlots = 0; // (wave-uniform: scalar registers)
+    uint32_t ctrVertices = 0, ctrShadow = 0; // per lane and launch (diagnostic counters: one register each, not two, in a loop that is short of them)
     const bool counting = args.counters != nullptr;
     // Small scenes of ONE light --
     // the kernel instance launched for them: the extension ray is sampled in the same visit of the light / BSDF blocks as the light.
@@ -1461,8 +1464,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 L = L + T * f3(bg.x, bg.y, bg.z);
                 pathDone = true;
             } else {
-                if (counting)
-                    ctrVertices += 1;
+                ctrVertices += 1; // (unconditionally: an inline constant, where `counting` as an addend would be one more live register)
                 const F3 view = d;
                 vP = O + d * hit.t; // Raytracer.cpp:134-135
                 vN = hitNormal(sc, lds, hit, O, d);
@@ -1653,8 +1655,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         if (!(pl == 0.0f || pb == 0.0f || (cosL == 0.0f && KAJO_IS_A_NUMBER(pb)))) { // (such a sample adds nothing whatever its shadow ray finds; see the loop further down)
                             const DFloat4 le = lds.lightEmission[k];
                             pendContrib = ((rrcp(pb + pl) * fl) * cosL) * f3(le.x, le.y, le.z);
-                            if (counting)
-                                ctrShadow += 1;
+                            ctrShadow += 1;
                             hasQ = lightReachedHead(sc, lds, k, si, O, d, keyL);
                             if (hasQ) {
                                 const uint32_t bin = shadowBin(sc, lc, k, O, reach);
@@ -1836,8 +1837,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     // until args.thrL lanes want them the walk runs for those lanes at once. STRICT +6.4 % on spheres.json, +20 %
                     // with three lights (profiles/r04_inline_shadow.txt). The FAST loop does not have the registers for it: at
                     // five waves per SIMD it spills 47 (-26 %), at four it loses the fifth wave (-10 %).
-                    if (counting)
-                        ctrShadow += 1;
+                    ctrShadow += 1;
                     const Hit sh = trace<false>(sc, lds, O, l);
                     if (sh.id == np + 1 + si) {
 #if KAJO_RSTRICT

@@ -3,6 +3,9 @@
 // what only scales radiance (integrator.inc.hip, KAJO_RSTRICT). Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
 #define KAJO_STRICT 1
 #define KAJO_EXACT 1
+#ifndef KAJO_WAVES_PER_SIMD
+#define KAJO_WAVES_PER_SIMD 5 // the EXACT loop of small scenes fits 96 VGPRs without vector spills (tools/kernel_resources.sh): +8 % over four waves
+#endif
 #ifndef KAJO_INLINE_SHADOW
 #define KAJO_INLINE_SHADOW 1 // small scenes of several lights answer shadow rays inside the light loop, as the STRICT build does
 #endif

@@ -1,6 +1,6 @@
 """In-kernel block profile of the render kernel (diagnostic build: `make -C kajo_amd/csrc prof`, run with
 KAJO_HIP_LIB=kajo_amd/libkajo_hip_prof.so). Shares of a loop trip per block and the lanes active in each.
-usage: blockprof.py [fast|strict] [spheres|caustics|stress] [W H passes]"""
+usage: blockprof.py [fast|strict|exact] [spheres|caustics|stress] [W H passes]"""
 import sys, os, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -26,7 +26,7 @@ W, H, passes = (int(a) for a in sys.argv[3:6]) if len(sys.argv) > 5 else (1920, 
 z = np.load(os.path.join(ROOT, 'tests/golden/scenes.npz'))
 a169 = Scene.from_npz(z, 'spheres_a169/', 's')
 sc = {'spheres': a169, 'caustics': Scene.from_npz(z, 'caustics_a169/', 'c'), 'stress': stress_scene(a169, 1000, 16)}[which]
-with HipRenderer(sc, W, H, counters=True, strict=(mode == 'strict'), flags=(capi.KAJO_FLAG_DEFERRED if DEFERRED else 0)) as r:
+with HipRenderer(sc, W, H, counters=True, strict=(mode == 'strict'), exact=(mode == 'exact'), flags=(capi.KAJO_FLAG_DEFERRED if DEFERRED else 0)) as r:
     r.render(passes).wait()
     c = r.counters()
     out = (C.c_ulonglong * 28)()

@@ -3,7 +3,7 @@
 # resource-usage remarks (no GPU needed). Usage: tools/kernel_resources.sh [extra hipcc flags, e.g. -DKAJO_PROFILE]
 HERE=$(cd "$(dirname "$0")/.." && pwd)
 C=$HERE/kajo_amd/csrc
-for k in fast strict; do
+for k in fast strict exact; do
   FP=$([ $k = fast ] && echo -ffp-contract=fast || echo -ffp-contract=off)
   hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$HERE/include -I$C -fno-slp-vectorize $FP \
     $([ $k = fast ] && echo "-mllvm -amdgpu-sched-strategy=max-ilp") "$@" -Rpass-analysis=kernel-resource-usage -c $C/kernel_$k.hip -o /dev/null 2>&1 |

@@ -132,13 +132,23 @@ struct Scheduler::Impl
             throw std::runtime_error("hip::Scheduler: no GPU visible (this backend has no CPU path)");
         if (opt.sameDevice && opt.gather != Options::Copy)
             throw std::runtime_error("hip::Scheduler: sameDevice needs gather = Copy (RCCL wants one rank per device)");
+        Options::Numerics numerics = opt.strict ? Options::Strict : opt.numerics;
+        if (opt.numericsFromEnvironment) {
+            if (const char* e = std::getenv("KAJO_HIP_NUMERICS")) {
+                const std::string v(e);
+                if (v == "exact") numerics = Options::Exact;
+                else if (v == "fast") numerics = Options::Fast;
+                else if (v == "strict") numerics = Options::Strict;
+                else throw std::runtime_error("hip::Scheduler: KAJO_HIP_NUMERICS must be exact, fast or strict");
+            }
+        }
         for (int g = 0; g < opt.gpus; g++) {
             KajoParams p;
             kajo_hip_default_params(&p);
             p.samplesPerPass = opt.samplesPerPass;
             p.depthLimit = opt.depthLimit;
             p.seed = opt.seed;
-            p.flags = (opt.strict ? KAJO_FLAG_STRICT : 0u) | (opt.counters ? KAJO_FLAG_COUNTERS : 0u);
+            p.flags = (numerics == Options::Strict ? KAJO_FLAG_STRICT : numerics == Options::Exact ? KAJO_FLAG_EXACT : 0u) | (opt.counters ? KAJO_FLAG_COUNTERS : 0u);
             p.device = opt.sameDevice ? 0 : g;
             p.tileIndex = g;
             p.tileCount = opt.gpus;
@@ -211,7 +221,17 @@ struct Scheduler::Impl
     bool composed = false;
 };
 
-Scheduler::Scheduler(const scene::Scene& scene, Image* image, Preview* preview): Scheduler(scene, image, preview, Options())
+namespace
+{
+Options optionsOfTheThreeArgumentForm()
+{
+    Options o; // every visible GPU (gpus = 0), reference constants, EXACT numerics unless KAJO_HIP_NUMERICS says otherwise
+    o.numericsFromEnvironment = true;
+    return o;
+}
+} // namespace
+
+Scheduler::Scheduler(const scene::Scene& scene, Image* image, Preview* preview): Scheduler(scene, image, preview, optionsOfTheThreeArgumentForm())
 {
 }
 

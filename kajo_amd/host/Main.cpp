@@ -42,7 +42,9 @@ int main(int argc, char** argv)
                         "    --scene-pod F   read the scene as a flat binary image of scene::Scene (int32 nSpheres, nPlanes; background 4 f32;\n"
                         "                    view 16; projection 16; spheres 39 f32 each; planes 38 f32 each) instead of a JSON file\n"
                         "    --batch N       passes per image refresh (0 = automatic: 16 headless, a 30 Hz refresh with a preview)\n"
-                        "    --strict        strict numerics\n"
+                        "    --exact         numerics: the reference's decisions on every path, fast arithmetic for radiance only (default)\n"
+                        "    --fast          numerics: hardware transcendentals and contraction everywhere (1.6 x the rate, RMSE ~6e-4)\n"
+                        "    --strict        numerics: the CPU oracle bit for bit\n"
                         "    --gather MODE   rccl | copy (multi-GPU gather transport)\n"
                         "    --same-device   put every tile owner on GPU 0 (testing; implies --gather copy)\n"
                         "    --force-gather  run the gather + compose step with one GPU too (testing: the RCCL call sequence at N = 1)\n"
@@ -61,7 +63,9 @@ int main(int argc, char** argv)
         else if (a == "--seed" && more) opt.seed = std::strtoull(args[++i].c_str(), nullptr, 0);
         else if (a == "--gpus" && more) opt.gpus = std::atoi(args[++i].c_str());
         else if (a == "--batch" && more) opt.passesPerUpdate = std::atoi(args[++i].c_str());
-        else if (a == "--strict") opt.strict = true;
+        else if (a == "--strict") opt.numerics = hip::Options::Strict;
+        else if (a == "--exact") opt.numerics = hip::Options::Exact;
+        else if (a == "--fast") opt.numerics = hip::Options::Fast;
         else if (a == "--gather" && more) opt.gather = args[++i] == "copy" ? hip::Options::Copy : hip::Options::Rccl;
         else if (a == "--same-device") { opt.sameDevice = true; opt.gather = hip::Options::Copy; }
         else if (a == "--force-gather") opt.forceGather = true;

@@ -53,7 +53,7 @@ def test_driver_matches_c_abi(tmp_path, scenes):
     import numpy as _np
     z = _np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
     strict_parse = Scene.from_npz(z, "caustics_a169/strict_")  # what the host loader produces, bit for bit
-    with HipRenderer(strict_parse, 96, 54) as r:
+    with HipRenderer(strict_parse, 96, 54, exact=True) as r:  # hip::Options::numerics defaults to Exact (round 5)
         want = r.render(2).radiance()
         px = r.argb8()
     assert np.array_equal(acc.view(np.uint32), want.view(np.uint32))
@@ -101,13 +101,34 @@ def test_three_argument_constructor_takes_the_whole_node(tmp_path, scenes):
     # refresh renders as many passes as fit a 30 Hz frame, so it may overshoot by part of a batch, as the reference's loop does)
     assert stats["gpus"] == torch.cuda.device_count() and 3 <= stats["passes"] <= 3 + 16
     acc = np.fromfile(raw, np.float32).reshape(90, 160, 4)
-    with HipRenderer(sc, 160, 90) as r:
+    with HipRenderer(sc, 160, 90, exact=True) as r:  # the form's numerics: EXACT (the reference's decisions on every path)
         want = r.render(stats["passes"]).radiance()
     assert np.array_equal(acc.view(np.uint32), want.view(np.uint32))
+    # ... unless the environment names another build (the form has no options)
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=dict(env, KAJO_HIP_NUMERICS="fast"))
+    assert p.returncode == 0, p.stderr
+    n_fast = json.loads(p.stdout.strip().splitlines()[-1])["passes"]
+    with HipRenderer(sc, 160, 90) as r:
+        want = r.render(n_fast).radiance()
+    assert np.array_equal(np.fromfile(raw, np.float32).reshape(90, 160, 4).view(np.uint32), want.view(np.uint32))
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=dict(env, KAJO_HIP_NUMERICS="double"))
+    assert p.returncode == 2 and "KAJO_HIP_NUMERICS" in p.stderr
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=dict(env, KAJO_HIP_GPUS="1"))
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["gpus"] == 1
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=dict(env, KAJO_HIP_GPUS=str(torch.cuda.device_count() + 1)))
     assert p.returncode == 2 and "KAJO_HIP_GPUS" in p.stderr
+
+
+def test_driver_numerics_flags(tmp_path):
+    """kajo_render --fast / --exact (default) / --strict select the three numerics builds of include/kajo_hip.h."""
+    from kajo_amd.scene import Scene
+    z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
+    sc = Scene.from_npz(z, "caustics_a169/strict_")
+    for flag, kw in (("--fast", {}), ("--exact", {"exact": True}), ("--strict", {"strict": True})):
+        acc, _, _ = run(tmp_path, flag)
+        with HipRenderer(sc, 96, 54, **kw) as r:
+            want = r.render(2).radiance()
+        assert np.array_equal(acc.view(np.uint32), want.view(np.uint32)), flag
 
 
 def test_driver_matches_oracle_strict(tmp_path):

@@ -163,6 +163,19 @@ int kajo_hip_stage_scene(const KajoScene* scene, float* invDet17, float* basis12
 int kajo_hip_stage_shadow_lists(const KajoScene* scene, int32_t* binsPerAxis, int32_t* nLights, int32_t* lightSphere, uint32_t* start,
                                 size_t startCapacity, float* key, uint32_t* index, size_t itemCapacity);
 
+/* Host-only helper (no GPU needed), for tests: what create() decides about a scene's culling structures (kajo_amd/csrc/stage.cpp).
+   closedRoom: the planes, all opaque, leave a BOUNDED convex region around the camera -- every ray of every path starts inside it;
+   room[6] its bounding box widened to hold every sphere (min xyz, max xyz). grid: the uniform grid is built (>= 48 spheres, all of
+   determinant 1, rigid planes); gridReach: rays starting farther than this from gridCenter walk every sphere instead (the grid's
+   margins are sized for nearer ones); 0 = no limit (closed room). shadowLists: per-light visibility lists are built (they need the
+   closed room: their margins are sized from its extent). */
+typedef struct KajoStageInfo {
+    int32_t closedRoom, grid, shadowLists, reserved;
+    float room[6];
+    float gridCenter[3], gridReach;
+} KajoStageInfo;
+int kajo_hip_stage_info(const KajoScene* scene, KajoStageInfo* out);
+
 /* Known-answer hooks: run the kernels' OWN device functions on caller-supplied rays, so that the
    vectors captured from the compiled reference (tests/golden/kat_trace.npz, kat_shade.npz) can be
    checked on the GPU function by function. All pointers are HOST memory; scenes whose hot records

@@ -37,8 +37,13 @@ EXPORTS = [
     "kajo_hip_reset", "kajo_hip_set_pass_count", "kajo_hip_resolve_argb8", "kajo_hip_read_radiance", "kajo_hip_resolve_argb8_device",
     "kajo_hip_tile_buffer", "kajo_hip_compose", "kajo_hip_set_stream", "kajo_hip_counters",
     "kajo_hip_stage_scene", "kajo_hip_last_error", "kajo_hip_version", "kajo_hip_kat_trace", "kajo_hip_kat_shade",
-    "kajo_hip_kat_strictmath", "kajo_hip_stage_shadow_lists", "kajo_hip_resolve_gathered_argb8_device",
+    "kajo_hip_kat_strictmath", "kajo_hip_stage_shadow_lists", "kajo_hip_resolve_gathered_argb8_device", "kajo_hip_stage_info",
 ]
+
+
+class KajoStageInfo(C.Structure):
+    _fields_ = [("closedRoom", C.c_int32), ("grid", C.c_int32), ("shadowLists", C.c_int32), ("reserved", C.c_int32),
+                ("room", C.c_float * 6), ("gridCenter", C.c_float * 3), ("gridReach", C.c_float)]
 
 
 class KajoParams(C.Structure):
@@ -102,6 +107,8 @@ def lib():
         if hasattr(L, "kajo_hip_stage_shadow_lists"):  # (round 4; the experiment libraries of earlier rounds do not have it)
             L.kajo_hip_stage_shadow_lists.argtypes = [C.POINTER(KajoScene), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p, C.c_void_p,
                                                       C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        if hasattr(L, "kajo_hip_stage_info"):
+            L.kajo_hip_stage_info.argtypes = [C.POINTER(KajoScene), C.POINTER(KajoStageInfo)]
         L.kajo_hip_kat_trace.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         L.kajo_hip_kat_shade.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.kajo_hip_kat_strictmath.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

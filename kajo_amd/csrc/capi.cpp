@@ -329,6 +329,25 @@ int kajo_hip_stage_shadow_lists(const KajoScene* scene, int32_t* binsPerAxis, in
     return (int)st.shadowItems.size();
 }
 
+int kajo_hip_stage_info(const KajoScene* scene, KajoStageInfo* info)
+{
+    if (!scene || !info)
+        return fail(KAJO_E_INVALID, "null argument");
+    kajo::StagedScene st;
+    kajo::stageScene(*scene, st);
+    std::memset(info, 0, sizeof *info);
+    info->closedRoom = st.roomClosed ? 1 : 0;
+    info->grid = st.gridEnabled ? 1 : 0;
+    info->shadowLists = st.shadowEnabled ? 1 : 0;
+    for (int k = 0; k < 3; k++) {
+        info->room[k] = (float)st.roomLo[k];
+        info->room[3 + k] = (float)st.roomHi[k];
+        info->gridCenter[k] = st.gridCenter[k];
+    }
+    info->gridReach = (st.gridEnabled && !st.roomClosed) ? std::sqrt(st.gridReach2) : 0.f;
+    return KAJO_OK;
+}
+
 int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoParams* params, kajo_hip_t* out)
 {
     if (!scene || !params || !out)
@@ -415,7 +434,9 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
             v.grid.bmax[k] = st.gridEnabled ? st.gridMax[k] : 0.f;
             v.grid.cell[k] = st.gridEnabled ? st.gridCell[k] : 1.f;
             v.grid.invCell[k] = st.gridEnabled ? 1.f / st.gridCell[k] : 1.f;
+            v.grid.center[k] = st.gridCenter[k];
         }
+        v.grid.reach2 = st.gridReach2;
     }
     {
         const uint32_t* start = nullptr;
@@ -480,7 +501,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     KAJO_TUNE_INT("KAJO_THR_L", 1, 65, h->thrL);
     KAJO_TUNE_INT("KAJO_HOLD_TRIPS", 1, 16, h->holdTrips);
     size_t gridBytes = 0;
-    const size_t gridHeaderBytes = st.gridEnabled ? 4 * 16 : 0; // always in LDS (integrator.inc.hip gridWalk)
+    const size_t gridHeaderBytes = st.gridEnabled ? 5 * 16 : 0; // always in LDS (integrator.inc.hip gridWalk)
     if (st.gridEnabled) {
         gridBytes = ((st.gridCellStart.size() * sizeof(uint32_t) + st.gridItems.size() * sizeof(uint16_t)) + 15) & ~(size_t)15;
         // The DDA reads a cell record and an item per step, each a dependent load: ~64 cycles from LDS, ~500 from L2. But the

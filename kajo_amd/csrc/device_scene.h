@@ -86,6 +86,10 @@ struct DGrid
     const uint16_t* items;     // sphere indices (16 bits: the hot records of 65536 spheres would not fit LDS anyway), ascending within a cell
     int32_t nCells, nItems;
     int32_t inLds;             // the two arrays are staged into LDS behind the hot records
+    // The registration margins cover what binary32 rounding lets the reference's sphere test report as a hit (stage.cpp
+    // floatHitSlack) for rays that start within sqrt(reach2) of `center`; a ray from farther out (a vertex far away on an open
+    // floor) walks every sphere instead. 3e38 when the planes close the scene in (stage.cpp findRoom): no ray starts outside.
+    float center[3], reach2;
 };
 
 // Per-light visibility lists (large scenes whose spheres are all world-space balls; stage.cpp buildShadowLists). A shadow ray

@@ -245,7 +245,7 @@ struct LdsScene
     const DFloat4* camera;         // [7] p1, p2 - p1, p3 - p1, origin (Renderer.cpp:29-34), background, the pixel / sample sizes of
                                    // Renderer.cpp:39-42, stream key words + W + H: read where a camera ray is formed /
                                    // a ray escapes, instead of fifteen scalar registers held through the whole loop (the loop spills SGPRs)
-    const DFloat4* gridHeader;     // [4] (bmin, dim.x), (bmax, dim.y), (cell, dim.z), (1 / cell, -): LDS, read at the start of a walk
+    const DFloat4* gridHeader;     // [5] (bmin, dim.x), (bmax, dim.y), (cell, dim.z), (1 / cell, -), (centre, reach^2): LDS, read at the start of a walk
     // The grid's cell lists, as staged into LDS when they fit (DGrid.inLds; else they are read from sc.grid's global arrays).
     // The two homes are kept in SEPARATE pointers and the walk is instantiated once per home: a pointer that may be either
     // compiles to FLAT loads with a full `s_waitcnt vmcnt(0) lgkmcnt(0)` behind each -- which is what round 2's walk paid for
@@ -382,7 +382,13 @@ KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* 
         if (sc.allTranslated) {
             // (centre, radius) spheres with the bookkeeping of the brute-force walk: the smaller non-negative root is
             // the smaller bit pattern, "exists, not behind, closer" one unsigned compare (plus the tie rule)
-            uint32_t kMax = __builtin_bit_cast(uint32_t, tMax);
+            // Closest wins; among bit-identical distances the LATER object (Raytracer.cpp:115 rejects only t > max, objects in scene
+            // order) -- whatever the order the cells deliver them in. (distance pattern, ~id) as ONE 64-bit key, smaller wins: a
+            // sphere ties over a plane and over a lower-index sphere, and a sphere met again in a later cell (same key) changes
+            // nothing. One 64-bit compare where round 3-4 had a 32-bit one that gave ties to the object met first.
+            uint64_t key = ((uint64_t)__builtin_bit_cast(uint32_t, tMax) << 32) | (uint32_t)~best;
+            uint32_t nidBase = ~(uint32_t)(np + 1);
+            asm volatile("" : "+v"(nidBase)); // (one v_sub per item: left to itself the compiler re-derives -(np + i) - 2 in three)
             for (uint32_t k = k0; k < e; k++) {
                 const int i = (int)gridItems[k];
                 const DFloat4 s = lds.sphereHot[i];
@@ -392,14 +398,11 @@ KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* 
                 float sq = ksqrt(h * h - aT * c);
                 const uint32_t klo = __builtin_bit_cast(uint32_t, (-h - sq) * iaT), khi = __builtin_bit_cast(uint32_t, (sq - h) * iaT);
                 const uint32_t kth = klo < khi ? klo : khi;
-                // (a sphere met again in a later cell returns the distance it already holds: no change either way. Two
-                // DIFFERENT objects at a bit-identical distance would go to the later one in the every-object walk and to the
-                // first one here; FAST accepts that for three instructions less per test.)
-                const bool ok = kth < kMax;
-                kMax = ok ? kth : kMax;
-                best = ok ? np + 1 + i : best;
+                const uint64_t cand = ((uint64_t)kth << 32) | (nidBase - (uint32_t)i); // ~(np + 1 + i)
+                key = cand < key ? cand : key;
             }
-            tMax = __builtin_bit_cast(float, kMax);
+            tMax = __builtin_bit_cast(float, (uint32_t)(key >> 32));
+            best = (int)~(uint32_t)key;
             bestT0 = tMax;
         } else
 #endif
@@ -527,9 +530,17 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
         if (!(aT == aT) && ns > 0)
             return Hit{np + ns, aT, aT};
 #endif
-        if (hasRay)
-            gridWalk<GHOME>(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
-        return Hit{best, tMax, bestT0};
+        // The grid's margins are sized for rays that start within `reach` of the spheres' centre (device_scene.h DGrid: what
+        // rounding lets the reference's test report as a hit grows with |O - c|^2). A ray from farther out -- a vertex far away on
+        // an open floor; never in a closed room -- takes its wave to the every-sphere loop below, which needs no margin.
+        const DFloat4 gc = lds.gridHeader[4];
+        const float fx = O.x - gc.x, fy = O.y - gc.y, fz = O.z - gc.z;
+        const bool far = hasRay && !(fx * fx + fy * fy + fz * fz <= gc.w);
+        if (__builtin_amdgcn_ballot_w64(far) == 0ull) {
+            if (hasRay)
+                gridWalk<GHOME>(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
+            return Hit{best, tMax, bestT0};
+        }
     }
 #if !KAJO_STRICT
     if (sc.allTranslated) {
@@ -1099,9 +1110,10 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
         gh[1] = DFloat4{g.bmax[0], g.bmax[1], g.bmax[2], __builtin_bit_cast(float, g.dim[1])};
         gh[2] = DFloat4{g.cell[0], g.cell[1], g.cell[2], __builtin_bit_cast(float, g.dim[2])};
         gh[3] = DFloat4{g.invCell[0], g.invCell[1], g.invCell[2], 0.0f};
+        gh[4] = DFloat4{g.center[0], g.center[1], g.center[2], g.reach2};
     }
     // the cell lists behind the header, when they fit (the pointers are formed either way; they are followed only if inLds)
-    uint32_t* cs = reinterpret_cast<uint32_t*>(gh + 4);
+    uint32_t* cs = reinterpret_cast<uint32_t*>(gh + 5);
     uint16_t* it = reinterpret_cast<uint16_t*>(cs + sc.grid.nCells + 1);
     lds.gridCellStartLds = cs;
     lds.gridItemsLds = it;

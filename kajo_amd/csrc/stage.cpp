@@ -169,17 +169,153 @@ DMaterial stageMaterial(const KajoMaterial& k)
 
 // World-space bounding box of sphere i: the unit-radius-r sphere under M is an ellipsoid whose
 // half-extent along world axis k is r * |row k of mat3(M)|.
-void sphereBounds(const KajoSphere& sp, float lo[3], float hi[3])
+// `E`: what binary32 rounding can add to r^2 - (distance of the ray's line from the centre)^2, the quantity whose sign decides
+// "hit" in Raytracer.cpp:26-30, for ray origins up to the distance the caller sized it for (floatHitSlack below): the reference
+// reports a hit on a sphere the exact line misses by up to sqrt(r^2 + E) - r, and a culling structure must not hide that sphere.
+void sphereBounds(const KajoSphere& sp, double E, float lo[3], float hi[3])
 {
     const Mat4 M = load(sp.transform);
     for (int k = 0; k < 3; k++) {
-        const double e = (double)sp.radius * std::sqrt((double)M.e(0, k) * M.e(0, k) + (double)M.e(1, k) * M.e(1, k) +
-                                                        (double)M.e(2, k) * M.e(2, k));
+        const double e0 = (double)sp.radius * std::sqrt((double)M.e(0, k) * M.e(0, k) + (double)M.e(1, k) * M.e(1, k) +
+                                                         (double)M.e(2, k) * M.e(2, k));
+        const double e = std::sqrt(e0 * e0 + E);
         const double c = M.e(3, k);
         const double pad = 1e-4 * (e + std::fabs(c)) + 1e-5; // registration margin >> float rounding of the DDA
         lo[k] = (float)(c - e - pad);
         hi[k] = (float)(c + e + pad);
     }
+}
+
+// Rounding of the discriminant b^2 - 4ac of Raytracer.cpp:26-30 in units of (4a): with o = O - c, |d| = 1 the terms are b^2 ~
+// 4 (d.o)^2 and 4ac ~ 4 (|o|^2 - r^2), each a sum of three products rounded to binary32 (relative 2^-24 per operation, ~1e-6 |o|^2
+// in all after the squaring of b) -- 8e-7 |o|^2 per unit of 4a, doubled for safety. `reach`: the largest |O - c| it must cover.
+double floatHitSlack(double reach)
+{
+    return 1.6e-6 * reach * reach;
+}
+
+// Where can a ray of a path START? At the camera, on a sphere, or on a plane -- and a point of a plane can be arbitrarily far away
+// unless the planes close the scene in. The convex region the planes leave around the camera (every plane taken on the camera's
+// side, as an unbounded two-sided plane is seen from there): when it is BOUNDED -- a room, as in every scene of the reference's
+// data/ -- and no plane lets light through (Shader.cpp:130-151), each ray of each path starts inside it (the first plane a ray from
+// inside meets is on its boundary, and an opaque plane sends the path back in), and its bounding box, widened to hold every sphere,
+// bounds |O - c| for the culling structures below. Vertices by intersecting plane triples; bounded iff it has a vertex (is
+// pointed) and no direction n_i x n_j stays inside all half-spaces.
+void findRoom(const KajoScene& s, StagedScene& out)
+{
+    out.roomClosed = false;
+    const int np = s.nPlanes;
+    if (np < 4 || np > 64)
+        return;
+    for (int i = 0; i < np; i++) {
+        const float* tr = s.planes[i].material.transparency;
+        if (tr[0] != 0.f || tr[1] != 0.f || tr[2] != 0.f || !(tr[0] == tr[0] && tr[1] == tr[1] && tr[2] == tr[2]))
+            return; // a path can pass through this plane and go on outside
+    }
+    double cam[3];
+    {
+        const Mat4 view = load(s.camera.transform);
+        const float zero[4] = {0.f, 0.f, 0.f, 1.f};
+        float o[4];
+        transform(inverse(view), zero, o);
+        for (int k = 0; k < 3; k++)
+            cam[k] = o[k];
+    }
+    std::vector<double> n(4 * (size_t)np); // s_i * (row y of the inverse): g_i(P) = n.P + n[3] > 0 on the camera's side
+    for (int i = 0; i < np; i++) {
+        const DFloat4 r = out.planeRow[i];
+        double g = (double)r.x * cam[0] + (double)r.y * cam[1] + (double)r.z * cam[2] + r.w;
+        const double len = std::sqrt((double)r.x * r.x + (double)r.y * r.y + (double)r.z * r.z);
+        if (!(len > 1e-12) || !(std::fabs(g) > 1e-6 * len))
+            return; // a degenerate plane, or the camera on a plane
+        const double sg = (g > 0 ? 1.0 : -1.0) / len;
+        n[4 * i] = sg * r.x, n[4 * i + 1] = sg * r.y, n[4 * i + 2] = sg * r.z, n[4 * i + 3] = sg * r.w;
+    }
+    auto inside = [&](const double P[3], double tol) {
+        for (int m = 0; m < np; m++)
+            if (n[4 * m] * P[0] + n[4 * m + 1] * P[1] + n[4 * m + 2] * P[2] + n[4 * m + 3] < -tol)
+                return false;
+        return true;
+    };
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300}, scale = 1.0;
+    for (int k = 0; k < 3; k++)
+        scale = std::fmax(scale, std::fabs(cam[k]));
+    int vertices = 0;
+    for (int i = 0; i < np; i++)
+        for (int j = i + 1; j < np; j++) {
+            const double* a = &n[4 * i];
+            const double* b = &n[4 * j];
+            const double u[3] = {a[1] * b[2] - a[2] * b[1], a[2] * b[0] - a[0] * b[2], a[0] * b[1] - a[1] * b[0]};
+            const double ul = std::sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+            if (ul > 1e-9) { // an edge direction: the region is unbounded if it, or its opposite, leaves through no plane
+                for (int sgn = -1; sgn <= 1; sgn += 2) {
+                    bool escapes = true;
+                    for (int m = 0; m < np && escapes; m++)
+                        escapes = sgn * (n[4 * m] * u[0] + n[4 * m + 1] * u[1] + n[4 * m + 2] * u[2]) >= -1e-9 * ul;
+                    if (escapes)
+                        return;
+                }
+            }
+            for (int k = j + 1; k < np; k++) {
+                const double* c = &n[4 * k];
+                const double det = c[0] * u[0] + c[1] * u[1] + c[2] * u[2];
+                if (!(std::fabs(det) > 1e-9))
+                    continue;
+                // x = -(a3 (b x c) + b3 (c x a) + c3 (a x b)) / det
+                const double bc[3] = {b[1] * c[2] - b[2] * c[1], b[2] * c[0] - b[0] * c[2], b[0] * c[1] - b[1] * c[0]};
+                const double ca[3] = {c[1] * a[2] - c[2] * a[1], c[2] * a[0] - c[0] * a[2], c[0] * a[1] - c[1] * a[0]};
+                double P[3];
+                for (int q = 0; q < 3; q++)
+                    P[q] = -(a[3] * bc[q] + b[3] * ca[q] + c[3] * u[q]) / det;
+                const double mag = std::fmax(scale, std::fmax(std::fabs(P[0]), std::fmax(std::fabs(P[1]), std::fabs(P[2]))));
+                if (!inside(P, 1e-7 * mag))
+                    continue;
+                vertices++;
+                for (int q = 0; q < 3; q++) {
+                    lo[q] = std::fmin(lo[q], P[q]);
+                    hi[q] = std::fmax(hi[q], P[q]);
+                }
+            }
+        }
+    if (vertices < 4)
+        return;
+    // A region that closes only far away -- two walls a rounding error from parallel meet 1e7 units out -- bounds nothing usefully:
+    // margins sized for it would put every sphere into every cell. Such a scene is treated as open (rays from far out walk every
+    // sphere); "far" = beyond 64 times the extent of the spheres and the camera.
+    {
+        double slo[3] = {cam[0], cam[1], cam[2]}, shi[3] = {cam[0], cam[1], cam[2]}, sd2 = 0, rd2 = 0;
+        for (int i = 0; i < s.nSpheres; i++) {
+            float bl[3], bh[3];
+            sphereBounds(s.spheres[i], 0.0, bl, bh);
+            for (int k = 0; k < 3; k++) {
+                slo[k] = std::fmin(slo[k], (double)bl[k]);
+                shi[k] = std::fmax(shi[k], (double)bh[k]);
+            }
+        }
+        for (int k = 0; k < 3; k++) {
+            sd2 += (shi[k] - slo[k]) * (shi[k] - slo[k]);
+            rd2 += (hi[k] - lo[k]) * (hi[k] - lo[k]);
+        }
+        if (!(rd2 <= 64.0 * 64.0 * std::fmax(sd2, 1e-6)))
+            return;
+    }
+    // (a sphere that a plane cuts, or that lies beyond one, is seen from inside all the same: the box holds them all)
+    for (int i = 0; i < s.nSpheres; i++) {
+        float bl[3], bh[3];
+        sphereBounds(s.spheres[i], 0.0, bl, bh);
+        for (int k = 0; k < 3; k++) {
+            lo[k] = std::fmin(lo[k], (double)bl[k]);
+            hi[k] = std::fmax(hi[k], (double)bh[k]);
+        }
+    }
+    for (int k = 0; k < 3; k++) {
+        if (!(lo[k] > -1e30 && hi[k] < 1e30))
+            return;
+        const double pad = 1e-6 * (std::fabs(lo[k]) + std::fabs(hi[k])) + 1e-6;
+        out.roomLo[k] = lo[k] - pad;
+        out.roomHi[k] = hi[k] + pad;
+    }
+    out.roomClosed = true;
 }
 
 void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
@@ -197,10 +333,48 @@ void buildGrid(const KajoScene& s, StagedScene& out, int gridMinSpheres)
     for (int i = 0; i < n; i++)
         if (out.invDet[17 * ((size_t)s.nPlanes + i) + 16] != 1.f)
             return;
+    // How far from the spheres a ray may start and still be answered through the grid: the registration margins are sized for it
+    // (floatHitSlack), and the walk sends a ray that starts farther out -- a vertex far away on an open floor -- to the every-sphere
+    // loop instead (integrator.inc.hip trace(): `far`). A closed room bounds every origin: nothing is ever sent there.
+    double center[3], half2 = 0;
+    {
+        double blo[3] = {1e300, 1e300, 1e300}, bhi[3] = {-1e300, -1e300, -1e300};
+        for (int i = 0; i < n; i++) {
+            float l[3], h[3];
+            sphereBounds(s.spheres[i], 0.0, l, h);
+            for (int k = 0; k < 3; k++) {
+                if (!(l[k] > -3e37f && h[k] < 3e37f))
+                    return; // non-finite geometry: keep the brute-force walk
+                blo[k] = std::fmin(blo[k], (double)l[k]);
+                bhi[k] = std::fmax(bhi[k], (double)h[k]);
+            }
+        }
+        for (int k = 0; k < 3; k++) {
+            center[k] = 0.5 * (blo[k] + bhi[k]);
+            half2 += 0.25 * (bhi[k] - blo[k]) * (bhi[k] - blo[k]);
+        }
+    }
+    double reach = 4.0 * std::sqrt(half2) + 1.0; // an open scene: origins up to twice the spheres' diameter from their centre
+    if (out.roomClosed) {
+        reach = 0;
+        for (int c = 0; c < 8; c++) {
+            double d2 = 0;
+            for (int k = 0; k < 3; k++) {
+                const double v = ((c >> k) & 1 ? out.roomHi[k] : out.roomLo[k]) - center[k];
+                d2 += v * v;
+            }
+            reach = std::fmax(reach, std::sqrt(d2));
+        }
+    }
+    // (|O - c_i| <= |O - centre| + |centre - c_i| <= reach + half diagonal)
+    const double E = floatHitSlack(reach * 1.0001 + std::sqrt(half2));
+    for (int k = 0; k < 3; k++)
+        out.gridCenter[k] = (float)center[k];
+    out.gridReach2 = out.roomClosed ? 3e38f : (float)(reach * reach);
     std::vector<float> lo(3 * (size_t)n), hi(3 * (size_t)n);
     float bmin[3] = {3e38f, 3e38f, 3e38f}, bmax[3] = {-3e38f, -3e38f, -3e38f};
     for (int i = 0; i < n; i++) {
-        sphereBounds(s.spheres[i], &lo[3 * i], &hi[3 * i]);
+        sphereBounds(s.spheres[i], E, &lo[3 * i], &hi[3 * i]);
         for (int k = 0; k < 3; k++) {
             if (!(lo[3 * i + k] > -3e37f && hi[3 * i + k] < 3e37f))
                 return; // non-finite geometry: keep the brute-force walk
@@ -298,7 +472,10 @@ void buildShadowLists(const KajoScene& s, StagedScene& out, bool wanted)
 {
     out.shadowEnabled = false;
     const int n = s.nSpheres, nL = (int)out.light.size();
-    if (!wanted || !out.gridEnabled || !out.allTranslated || nL == 0)
+    // (the lists answer a query from candidates chosen by geometry alone: they need a bound on where a shadow ray can start -- a
+    // closed room, findRoom -- to know how near a miss the reference's arithmetic can still report as a hit. Open scenes keep the
+    // grid walk for their shadow rays, which sends far origins to the every-sphere loop ray by ray.)
+    if (!wanted || !out.gridEnabled || !out.allTranslated || nL == 0 || !out.roomClosed)
         return;
     // bins per cube-face axis. 1000 spheres / 16 lights: 16 -> 15.1 candidate spheres per query, 0.9 MB of lists, 1.64 G paths/s;
     // 32 -> 7.8, 2.2 MB, 2.35 G; 64 -> 5.1, 6.8 MB, 2.74 G; 96 and 128 -> 2.3 G again (the lists fall out of the L2). The tube of
@@ -310,28 +487,12 @@ void buildShadowLists(const KajoScene& s, StagedScene& out, bool wanted)
     const size_t binsPerLight = (size_t)6 * N * N;
     if ((size_t)nL * binsPerLight > ((size_t)1 << 23))
         return;
-    // scene extent: sphere bounds and the camera
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int i = 0; i < n; i++)
-        for (int k = 0; k < 3; k++) {
-            const double c = load(s.spheres[i].transform).e(3, k), r = s.spheres[i].radius;
-            lo[k] = std::fmin(lo[k], c - r);
-            hi[k] = std::fmax(hi[k], c + r);
-        }
-    {
-        const Mat4 view = load(s.camera.transform);
-        const float zero[4] = {0.f, 0.f, 0.f, 1.f};
-        float o[4];
-        transform(inverse(view), zero, o);
-        for (int k = 0; k < 3; k++) {
-            lo[k] = std::fmin(lo[k], (double)o[k]);
-            hi[k] = std::fmax(hi[k], (double)o[k]);
-        }
-    }
+    // every shadow ray starts inside the room, every sphere lies inside it: |O - c| is at most the room's diagonal
+    // (rounds 1-4 took the extent of the spheres and the camera here, which a vertex far out on a plane exceeds: advisor finding)
     double diag2 = 0;
     for (int k = 0; k < 3; k++)
-        diag2 += (hi[k] - lo[k]) * (hi[k] - lo[k]);
-    const double E = 4e-7 * 4.0 * diag2; // rounding of b^2 - 4ac / 4a at twice the scene's diagonal, with a factor of two in hand
+        diag2 += (out.roomHi[k] - out.roomLo[k]) * (out.roomHi[k] - out.roomLo[k]);
+    const double E = floatHitSlack(std::sqrt(diag2));
     // bins: centre direction and bounding half-angle (as cosine / sine pairs are not needed: angles are compared directly)
     struct Bin
     {
@@ -516,6 +677,7 @@ void stageScene(const KajoScene& s, StagedScene& out, int gridMinSpheres, bool s
             out.light.push_back(i);
     }
 
+    findRoom(s, out);
     buildGrid(s, out, gridMinSpheres);
     buildShadowLists(s, out, shadowLists);
 

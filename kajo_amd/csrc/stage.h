@@ -24,8 +24,12 @@ struct StagedScene
     std::vector<DMaterial> material;
     std::vector<int32_t> light;
     std::vector<float> invDet; // 17 floats per object, planes first (debug / tests)
+    // the bounded convex region the planes leave around the camera, if there is one: every ray of every path starts inside it
+    bool roomClosed = false;
+    double roomLo[3] = {0, 0, 0}, roomHi[3] = {0, 0, 0};
     // uniform grid over the spheres (built when there are at least `gridMinSpheres` of them)
     bool gridEnabled = false;
+    float gridCenter[3] = {0, 0, 0}, gridReach2 = 3e38f; // rays starting farther than sqrt(gridReach2) from the centre walk every sphere
     int gridDim[3] = {0, 0, 0};
     float gridMin[3], gridMax[3], gridCell[3];
     std::vector<uint32_t> gridCellStart;

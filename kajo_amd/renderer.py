@@ -142,6 +142,16 @@ def stage_scene(scene: Scene):
     return inv, basis
 
 
+def stage_info(scene: Scene) -> dict:
+    """Host-only: what create() decides about the scene's culling structures (include/kajo_hip.h KajoStageInfo)."""
+    L = capi.lib()
+    pod = scene.pod()
+    info = capi.KajoStageInfo()
+    capi.check(L.kajo_hip_stage_info(C.byref(pod), C.byref(info)))
+    return dict(closed_room=bool(info.closedRoom), grid=bool(info.grid), shadow_lists=bool(info.shadowLists), room=np.array(info.room[:], np.float32),
+                grid_center=np.array(info.gridCenter[:], np.float32), grid_reach=float(info.gridReach))
+
+
 def stage_shadow_lists(scene: Scene):
     """Host-only: the per-light visibility lists create() stages for a large scene (device_scene.h DShadowLists), or None when
     the scene gets none. -> dict(n=bins per cube-face axis, lights=[sphere index], start=[nLights * 6 n^2 + 1], key, index)."""

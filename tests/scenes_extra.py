@@ -1,4 +1,4 @@
-"""Seeded scenes of the tools' own (whole_frame.py, oracle_vs_reference.py): not fixtures, generated where they are used."""
+"""Seeded scenes generated where they are used (tests/test_hip_whole_frames.py; tools/whole_frame.py, oracle_vs_reference.py): not fixtures."""
 import numpy as np
 from kajo_amd.scene import Scene
 

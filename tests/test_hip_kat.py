@@ -212,3 +212,13 @@ def test_light_sample_that_is_not_a_number(scenes):
     with HipRenderer(sc, W, H, spp=S, depth_limit=8, seed=seed, strict=True) as r:
         got, fin = r.kat_shade(rays[:, :3], rays[:, 3:], states)
     assert np.isnan(got).all() and np.array_equal(fin, want_fin)
+    with HipRenderer(sc, W, H, spp=S, depth_limit=8, seed=seed, exact=True) as r:  # EXACT decides (and poisons) as the oracle does
+        got, fin = r.kat_shade(rays[:, :3], rays[:, 3:], states)
+    assert np.isnan(got).all() and np.array_equal(fin, want_fin)
+    # FAST's stated deviation, pinned: its walk rejects a NaN distance by its bit pattern, so the poisoned shadow ray reaches nothing
+    # and the sample adds nothing -- the path goes on with the SAME draws (same final state here: nothing later in these two paths
+    # sits on a decision) and a finite radiance where the reference has NaN. Such pixels are counted in the bench's parity leg
+    # (nan_px 22 against the oracle's 34 on the configs[1] frame), not matched.
+    with HipRenderer(sc, W, H, spp=S, depth_limit=8, seed=seed) as r:
+        got, fin = r.kat_shade(rays[:, :3], rays[:, 3:], states)
+    assert np.isfinite(got).all() and np.array_equal(fin, want_fin)

@@ -1,0 +1,60 @@
+"""Whole frames against the oracle -- every pixel, not crops (crops hid three wrong pixels for three rounds: NaN light samples, one in
+1e8). Promoted in round 5 from tools/whole_frame.py, which recorded these comparisons in a text file nothing
+re-ran: BASELINE configs[3] (caustics: ideal-reflector wall, glass, Phong, three lights) at its 1920 x 1080, a generated scene of
+ROTATED spheres of every material with four lights (the general-sphere records, Raytracer.cpp:21-72 with a full inverse), and a
+300-sphere / 8-light scene (uniform grid + per-light visibility lists; Light.cpp:43-46's NaN samples of lights below the horizon).
+STRICT == oracle on every pixel, the same pixels not-a-number; EXACT: the same pixels not-a-number, the rest within rounding
+(no path decides differently: a flipped path moves its pixel by 1e-3 and more). The oracle needs 30-60 s of the host's cores per frame."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+from kajo_amd.renderer import HipRenderer
+from kajo_amd.scene import Scene, stress_scene
+from oraclelib import OracleLib, available
+from scenes_extra import mixed_scene
+from test_hip_workloads import SEED, clamped_rmse, record
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not available("oracle"), reason="oracle not built")]
+
+
+def host_threads():
+    from bench import host_cores
+    return max(1, min(host_cores(), 64))
+
+
+def cases(scenes):
+    base = scenes["spheres_a169"]
+    return {
+        "configs[3] caustics 1920x1080 x 16": (scenes["caustics_a169"], 1920, 1080, 16, 1e-6),
+        "rotated spheres of every material, 4 lights (mix:2) 1280x720 x 8": (mixed_scene(base, 2), 1280, 720, 8, 2e-6),
+        "300 spheres / 8 lights (scene seed 77) 1280x720 x 2": (stress_scene(base, 300, 8, seed=77), 1280, 720, 2, 5e-6),
+    }
+
+
+@pytest.mark.parametrize("name", ["configs[3] caustics 1920x1080 x 16", "rotated spheres of every material, 4 lights (mix:2) 1280x720 x 8",
+                                  "300 spheres / 8 lights (scene seed 77) 1280x720 x 2"])
+def test_whole_frame_strict_is_the_oracle_and_exact_decides_as_it_does(scenes, name):
+    sc, W, H, P, exact_rmse_bound = cases(scenes)[name]
+    t0 = time.time()
+    want = OracleLib("oracle").create(sc, 1).render(W, H, S=32, passes=P, seed=SEED, depth_limit=8, threads=host_threads())
+    t_oracle = time.time() - t0
+    nan_w = ~np.isfinite(want[..., :3]).all(-1)
+    with HipRenderer(sc, W, H, spp=32, depth_limit=8, seed=SEED, strict=True, passes_per_launch=P) as r:
+        got = r.render(P).radiance()
+    same = ((got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want)))[..., :3].all(-1)
+    assert same.all(), "%s: %d of %d pixels differ, first at %s" % (name, int((~same).sum()), same.size, np.argwhere(~same)[:4].tolist())
+    assert int((~np.isfinite(got[..., :3]).all(-1)).sum()) == int(nan_w.sum())
+    with HipRenderer(sc, W, H, spp=32, depth_limit=8, seed=SEED, exact=True, passes_per_launch=P) as r:
+        ex = r.render(P).radiance()
+    nan_e = ~np.isfinite(ex[..., :3]).all(-1)
+    assert np.array_equal(nan_e, nan_w), "%s: EXACT has %d not-a-number pixels, the oracle %d" % (name, int(nan_e.sum()), int(nan_w.sum()))
+    rm = clamped_rmse(ex[..., :3] / P, want[..., :3] / P)
+    off = int((np.abs(np.clip(ex[..., :3] / P, 0, 1) - np.clip(want[..., :3] / P, 0, 1)).max(-1) > 1e-3).sum())
+    record({"key": "whole frame: " + name, "px": int(same.size), "strict_px_bit_identical_to_oracle": int(same.sum()), "nan_px": int(nan_w.sum()),
+            "exact_vs_oracle_rmse": rm, "exact_px_off_by_more_than_1e-3": off, "oracle_seconds": round(t_oracle, 1)})
+    print("%s: STRICT %d / %d px bit-identical, %d NaN px on both sides; EXACT clamped RMSE %.3g, %d px off by > 1e-3; oracle %.0f s" % (
+        name, int(same.sum()), same.size, int(nan_w.sum()), rm, off, t_oracle))
+    assert rm < exact_rmse_bound and off == 0, (rm, off)

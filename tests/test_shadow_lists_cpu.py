@@ -138,3 +138,48 @@ def test_blockers_are_candidates_on_adversarial_geometry(scenes, seed):
             assert got[j] - 1 - np_ in index[lo:hi][key[lo:hi] <= reach[j]], (seed, k, j)
             checked += 1
     assert checked > 500
+
+
+def test_room_detection(scenes):
+    """stage.cpp findRoom: the culling structures' margins are sized from where a ray can START (what binary32 rounding lets the
+    reference's sphere test report as a hit grows with |O - c|^2, Raytracer.cpp:26-30). A bounded convex region of opaque planes
+    around the camera bounds it; anything else does not: then no visibility lists, and a grid that hands far rays to the
+    every-sphere loop (round-4 advisor finding: the margins were sized from the spheres' own extent, and a vertex 100 units out on
+    an open floor made the lists miss a quarter of the blockers)."""
+    from kajo_amd.renderer import stage_info
+    from kajo_amd.scene import Scene
+    base = scenes["spheres_a169"]
+    big = stress_scene(base, 300, 6, seed=7)
+    info = stage_info(big)
+    assert info["closed_room"] and info["grid"] and info["shadow_lists"] and info["grid_reach"] == 0.0
+    # spheres.json's room (data/spheres.json:42-79): x in [-8, 10], y in [-2, 1], z in [-2, 6]
+    assert np.allclose(info["room"], [-8, -2, -2, 10, 1, 6], atol=1e-3)
+    # five of the six walls: open to one side
+    for drop in range(6):
+        sc = Scene(big.background, big.view, big.proj, big.spheres, np.delete(big.planes, drop, 0), "open%d" % drop)
+        info = stage_info(sc)
+        assert not info["closed_room"] and not info["shadow_lists"] and info["grid"] and info["grid_reach"] > 10.0, drop
+        assert stage_shadow_lists(sc) is None
+    # a floor only
+    sc = Scene(big.background, big.view, big.proj, big.spheres, big.planes[:1], "floor")
+    assert not stage_info(sc)["closed_room"] and stage_shadow_lists(sc) is None
+    # a wall of glass: paths go on behind it
+    planes = big.planes.copy()
+    planes[3, 16 + 16:16 + 20] = (0.5, 0.5, 0.5, 1.0)  # Material.transparency (scene/Scene.h:11-23: ambient, diffuse, specular, emission, transparency)
+    sc = Scene(big.background, big.view, big.proj, big.spheres, planes, "glasswall")
+    assert stage_info(sc)["grid"] and not stage_info(sc)["closed_room"] and stage_shadow_lists(sc) is None
+    # the room turned as a whole (no axis-parallel wall): still a room, its box the turned room's
+    from scenes_extra import rotation
+    R = rotation(np.random.default_rng(4)).astype(np.float64)
+    planes = big.planes.copy()
+    spheres = big.spheres.copy()
+    for rec in (planes, spheres):
+        for k in range(len(rec)):
+            M = rec[k, :16].reshape(4, 4).T.astype(np.float64)  # column-major image -> matrix
+            rec[k, :16] = (R @ M).astype(np.float32).T.reshape(16)
+    view = (big.view.reshape(4, 4).T.astype(np.float64) @ np.linalg.inv(R)).astype(np.float32).T.reshape(16)
+    sc = Scene(big.background, view, big.proj, spheres, planes, "turned")
+    info = stage_info(sc)
+    assert info["closed_room"]
+    corners = np.array([[x, y, z, 1] for x in (-8, 10) for y in (-2, 1) for z in (-2, 6)], np.float64) @ R.T
+    assert np.allclose(info["room"][:3], corners[:, :3].min(0), atol=1e-2) and np.allclose(info["room"][3:], corners[:, :3].max(0), atol=1e-2)

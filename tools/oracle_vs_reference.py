@@ -2,7 +2,7 @@
 """The oracle (libm numerics) against the COMPILED REFERENCE (-O2 build, oracle/_ref) over a WHOLE frame, on the CPU: NaN pixels on both
 sides, bit-identical share, and the pixels whose relative difference says a path took another decision (none, if the oracle restates the
 reference). Needs oracle/_ref (the build container, or a GPU box the built libraries travelled to).
-usage: oracle_vs_reference.py <scene key of tests/golden/scenes.npz | mix:<scene seed> (tools/scenes_extra.py)> W H passes     e.g. spheres_a169 1920 1080 16 (2.5 min on 8 cores)"""
+usage: oracle_vs_reference.py <scene key of tests/golden/scenes.npz | mix:<scene seed> (tests/scenes_extra.py)> W H passes     e.g. spheres_a169 1920 1080 16 (2.5 min on 8 cores)"""
 import sys, time, os
 ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0]=[ROOT,os.path.join(ROOT,'tests')]

@@ -37,7 +37,7 @@ threading.Thread(target=_heartbeat, daemon=True).start()
 SEED = 0o715517
 
 
-from scenes_extra import mixed_scene
+from scenes_extra import mixed_scene  # (tests/scenes_extra.py)
 threads = max(1, min(host_cores(), 64))
 O = OracleLib("oracle")
 # (name, scene, W, H, passes, passes per launch[, S, depth limit])

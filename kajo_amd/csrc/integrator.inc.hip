@@ -533,10 +533,14 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
         // The grid's margins are sized for rays that start within `reach` of the spheres' centre (device_scene.h DGrid: what
         // rounding lets the reference's test report as a hit grows with |O - c|^2). A ray from farther out -- a vertex far away on
         // an open floor; never in a closed room -- takes its wave to the every-sphere loop below, which needs no margin.
-        const DFloat4 gc = lds.gridHeader[4];
-        const float fx = O.x - gc.x, fy = O.y - gc.y, fz = O.z - gc.z;
-        const bool far = hasRay && !(fx * fx + fy * fy + fz * fz <= gc.w);
-        if (__builtin_amdgcn_ballot_w64(far) == 0ull) {
+        // (reach2 = 3e38 -- the closed room of every scene in the reference's data/ -- skips the test: a scalar branch)
+        bool anyFar = false;
+        if (sc.grid.reach2 < 1e38f) {
+            const DFloat4 gc = lds.gridHeader[4];
+            const float fx = O.x - gc.x, fy = O.y - gc.y, fz = O.z - gc.z;
+            anyFar = __builtin_amdgcn_ballot_w64(hasRay && !(fx * fx + fy * fy + fz * fz <= gc.w)) != 0ull;
+        }
+        if (!anyFar) {
             if (hasRay)
                 gridWalk<GHOME>(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
             return Hit{best, tMax, bestT0};

@@ -72,8 +72,10 @@ extern "C" {
                                    oracle's objects, draws its random numbers and ends in its generator state; the fast forms where a value
                                    only scales radiance (BSDF values and pdfs, the light pdf, MIS weights, throughput products). The buffer
                                    differs from KAJO_FLAG_STRICT's in the last places of each path's radiance. Not with KAJO_FLAG_STRICT. */
-#define KAJO_FLAG_NO_ONE_LIGHT 256u /* small scenes with exactly one light, FAST numerics: run the kernel instance of any number of lights
-                                   instead of the one that samples the BSDF in the light's visit (same results; for A/B runs and tests) */
+#define KAJO_FLAG_NO_ONE_LIGHT 256u /* small scenes with exactly one light, every numerics build: run the kernel instance of any number of lights
+                                   (kajo_render_*_lights) instead of the one that samples the BSDF in the light's visit (same results in the
+                                   FAST and EXACT builds bit for bit and in the STRICT build, which stays the oracle; the hold thresholds
+                                   stay those of the scene's own instance; for A/B runs and tests) */
 
 typedef struct KajoParams {
     int32_t samplesPerPass; /* S: nominal samples per pixel per pass (reference: 32, Renderer.cpp:21);

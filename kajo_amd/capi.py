@@ -28,7 +28,7 @@ KAJO_FLAG_NO_SPLIT = 16
 KAJO_FLAG_COOP = 32      # experiment library libkajo_hip_r02.so only
 KAJO_FLAG_DEFERRED = 64  # experiment library libkajo_hip_exp.so only
 KAJO_FLAG_NO_SHADOW_LISTS = 128
-KAJO_FLAG_NO_ONE_LIGHT = 256
+KAJO_FLAG_NO_ONE_LIGHT = 256  # every numerics build: the any-number-of-lights instance for a one-light scene (A/B, tests)
 KAJO_FLAG_EXACT = 512  # decision-exact numerics: STRICT's decisions, FAST's radiance arithmetic
 
 # every symbol include/kajo_hip.h declares

@@ -1091,7 +1091,10 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
         const DSphereCold& c = sc.sphereCold[sc.light[L]];
         const DFloat4 r = sc.planeRow[pl];
         const float g = r.x * c.cx + r.y * c.cy + r.z * c.cz + r.w;
-        const float tol = 1.001f * c.radius + 1e-3f + 1e-5f * (__builtin_fabsf(r.x * c.cx) + __builtin_fabsf(r.y * c.cy) + __builtin_fabsf(r.z * c.cz) + __builtin_fabsf(r.w));
+        // (g is the plane's LOCAL y of the centre: the world distance times |row|. planesRigid only says det = 1 to rounding -- a plane
+        // scaled (2, .5, 1) passes -- so the ball's radius is measured in the same unit: round-4 advisor finding)
+        const float rowNorm = __builtin_sqrtf(r.x * r.x + r.y * r.y + r.z * r.z);
+        const float tol = 1.001f * c.radius * rowNorm + 1e-3f + 1e-5f * (__builtin_fabsf(r.x * c.cx) + __builtin_fabsf(r.y * c.cy) + __builtin_fabsf(r.z * c.cz) + __builtin_fabsf(r.w));
         lps[i] = (sc.planesRigid && g > tol) ? 1.0f : ((sc.planesRigid && g < -tol) ? -1.0f : 0.0f);
     }
     lds.lightPlaneSide = lps;

@@ -1,4 +1,5 @@
 // launch.inc.hip -- host-side launcher of the kernel defined by the including file.
+#include <mutex>
 #define KAJO_CAT2(a, b) a##b
 #define KAJO_CAT(a, b) KAJO_CAT2(a, b)
 
@@ -41,11 +42,15 @@ extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _split_launch)(const RenderArgs* args,
 extern "C" int KAJO_CAT(KAJO_KERNEL_NAME, _set_lds)(int coldInLds, size_t ldsBytes)
 {
     static size_t highWaterOfDevice[64][2] = {};
+    static std::mutex guard; // handles are created from any thread; the table and the attribute calls below are one critical section
     int device = 0;
     hipError_t e = hipGetDevice(&device);
     if (e != hipSuccess)
         return (int)e;
-    size_t* highWater = highWaterOfDevice[device & 63];
+    if (device < 0 || device >= 64)
+        return (int)hipErrorInvalidDevice; // (the table has 64 rows; ordinals are never aliased)
+    std::lock_guard<std::mutex> lock(guard);
+    size_t* highWater = highWaterOfDevice[device];
     const int k = coldInLds ? 1 : 0;
     if (ldsBytes <= highWater[k])
         return (int)hipSuccess;

@@ -133,6 +133,8 @@ struct Scheduler::Impl
         if (opt.sameDevice && opt.gather != Options::Copy)
             throw std::runtime_error("hip::Scheduler: sameDevice needs gather = Copy (RCCL wants one rank per device)");
         Options::Numerics numerics = opt.strict ? Options::Strict : opt.numerics;
+        if (opt.numericsFromEnvironment && std::getenv("KAJO_HIP_FORCE_GATHER"))
+            opt.forceGather = true; // (testing: the three-argument form's N > 1 code -- communicator, gather, resolve from the gathered buffers -- on a one-GPU box)
         if (opt.numericsFromEnvironment) {
             if (const char* e = std::getenv("KAJO_HIP_NUMERICS")) {
                 const std::string v(e);
@@ -273,15 +275,17 @@ void Scheduler::run()
     // Passes between two refreshes. Fusing passes into one launch evens out the lanes' trip counts (38 G paths/s at
     // 16 per launch against 30 at one), so headless runs take all that is left and a live preview
     // gets as many as fit a 30 Hz refresh, from the measured time per pass.
+    // A launch cannot be interrupted (the reference's workers look at their stop flag once per row, cpu/Renderer.cpp:77-78): the
+    // bound on how long run() can overshoot a closed window -- or a caller waits for the first image -- is the length of one
+    // launch. With a preview: a 30 Hz refresh. Headless: half a second (the 1000-sphere scene at 4K takes 37 ms per pass: 13
+    // passes per launch instead of 16, where round 4 launched 16 regardless -- 0.6 s -- and 32 in the tools: 1.2 s).
     double msPerPass = 0.0;
     auto autoBatch = [&]() {
         if (o.passesPerUpdate > 0)
             return o.passesPerUpdate;
-        if (!d.preview)
-            return 16;
         if (msPerPass <= 0.0)
-            return 1;
-        const int fit = (int)(33.0 / msPerPass);
+            return d.preview ? 1 : 2; // nothing measured yet
+        const int fit = (int)((d.preview ? 33.0 : 500.0) / msPerPass);
         return fit < 1 ? 1 : (fit > 16 ? 16 : fit);
     };
 

@@ -24,6 +24,7 @@ int main(int argc, char** argv)
     opt.gpus = 1;
     std::string podPath;
     bool verbose = false, json = false, threeArg = false;
+    int closeAtEvent = 0;
     for (size_t i = 1; i < args.size(); i++) {
         bool more = i + 1 < args.size();
         const std::string& a = args[i];
@@ -48,6 +49,7 @@ int main(int argc, char** argv)
                         "    --gather MODE   rccl | copy (multi-GPU gather transport)\n"
                         "    --same-device   put every tile owner on GPU 0 (testing; implies --gather copy)\n"
                         "    --force-gather  run the gather + compose step with one GPU too (testing: the RCCL call sequence at N = 1)\n"
+                        "    --close-at-event K  the headless preview's window closes at the K-th processEvents() call (testing: Esc mid-run)\n"
                         "    -o FILE         PNG output (out.png)\n"
                         "    --raw FILE      also dump the float4 accumulation (W*H*4 floats)\n"
                         "    --json          print run statistics as one JSON line\n"
@@ -70,6 +72,7 @@ int main(int argc, char** argv)
         else if (a == "--same-device") { opt.sameDevice = true; opt.gather = hip::Options::Copy; }
         else if (a == "--force-gather") opt.forceGather = true;
         else if (a == "--three-arg") threeArg = true;
+        else if (a == "--close-at-event" && more) closeAtEvent = std::atoi(args[++i].c_str());
         else if (a == "--scene-pod" && more) podPath = args[++i];
         else if (a == "-o" && more) out = args[++i];
         else if (a == "--raw" && more) rawOut = args[++i];
@@ -114,6 +117,7 @@ int main(int argc, char** argv)
     std::unique_ptr<Image> image(new Image(width, height));
     std::unique_ptr<Preview> preview(Preview::create(image.get(), true)); // as renderer/Main.cpp:132
     preview->setPassBudget(opt.passes, verbose);
+    preview->closeAtEvent(closeAtEvent);
     std::unique_ptr<Scheduler> scheduler;
     hip::Scheduler* hipScheduler = nullptr;
     opt.counters = json;
@@ -150,7 +154,15 @@ int main(int argc, char** argv)
         std::printf("], \"batch_passes\": [");
         for (size_t i = 0; i < s.batchPasses.size(); i++)
             std::printf("%s%d", i ? ", " : "", s.batchPasses[i]);
-        std::printf("]}\n");
+        // what the preview saw (renderer/Preview.cpp:79-98,216-234): every update() in call order, whether each came on the thread that
+        // owns the window, and how often it was asked for events
+        std::printf("], \"preview_updates\": [");
+        bool onOwner = true;
+        for (size_t i = 0; i < preview->updates().size(); i++) {
+            std::printf("%s%d", i ? ", " : "", preview->updates()[i].pass);
+            onOwner = onOwner && preview->updates()[i].onCreatingThread;
+        }
+        std::printf("], \"preview_updates_on_owning_thread\": %s, \"preview_event_calls\": %d}\n", onOwner ? "true" : "false", preview->eventCalls());
     }
     return 0;
 }

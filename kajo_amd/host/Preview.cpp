@@ -7,7 +7,8 @@
 #include <cstdio>
 
 Preview::Preview(Image* image):
-    m_image(image), m_budget(0), m_verbose(false), m_pass(0), m_samples(0), m_startTime(std::chrono::steady_clock::now())
+    m_image(image), m_budget(0), m_verbose(false), m_pass(0), m_samples(0), m_startTime(std::chrono::steady_clock::now()),
+    m_owner(std::this_thread::get_id())
 {
 }
 
@@ -26,12 +27,16 @@ void Preview::setPassBudget(int passes, bool verbose)
 
 bool Preview::processEvents()
 {
+    m_events++;
+    if (m_closeAt > 0 && m_events >= m_closeAt)
+        return false;
     return m_budget <= 0 || m_pass < m_budget;
 }
 
 void Preview::update(std::thread::id, int pass, int samples, int, int, int width, int height)
 {
     m_pass = pass;
+    m_updates.push_back(Update{pass, std::this_thread::get_id() == m_owner});
     m_samples += (long long)samples * width * height;
     if (m_verbose) {
         const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - m_startTime).count();

@@ -15,6 +15,7 @@
 #include <chrono>
 #include <memory>
 #include <thread>
+#include <vector>
 
 class Image;
 
@@ -29,6 +30,16 @@ public:
 
     // ---- headless driver only --------------------------------------------------------------
     void setPassBudget(int passes, bool verbose = false);
+    // The window "closes" at the k-th call of processEvents() (k >= 1: that call and every later one answer false) -- Esc pressed
+    // mid-run (renderer/Preview.cpp:216-234) -- whatever the pass count is then. 0 = never.
+    void closeAtEvent(int k) { m_closeAt = k; }
+    struct Update
+    {
+        int pass;
+        bool onCreatingThread; // update() must be called on the thread that owns the window (SDL: the main thread)
+    };
+    const std::vector<Update>& updates() const { return m_updates; }
+    int eventCalls() const { return m_events; }
     int pass() const { return m_pass; }
     // same accounting as the reference's Preview::update (renderer/Preview.cpp:81-82): samples * width * height per call
     long long nominalSamples() const { return m_samples; }
@@ -42,6 +53,9 @@ private:
     int m_pass;
     long long m_samples;
     std::chrono::steady_clock::time_point m_startTime;
+    int m_closeAt = 0, m_events = 0;
+    std::thread::id m_owner;
+    std::vector<Update> m_updates;
 };
 
 #endif

@@ -157,8 +157,8 @@ def test_shadow_lists_equal_the_grid_walk(O, scenes):
             assert a["vertices"] == b["vertices"]
 
 
-@pytest.mark.parametrize("strict", [False, True])
-def test_one_light_kernel_equals_the_general_one(scenes, strict):
+@pytest.mark.parametrize("numerics", ["fast", "strict", "exact"])
+def test_one_light_kernel_equals_the_general_one(scenes, numerics):
     """Small scenes with exactly one light run a kernel instance that samples the extension ray in the same visit of the
     light / BSDF blocks as the light (integrator.inc.hip PRESAMPLE) -- one visit per vertex instead of two (FAST), and the shadow
     ray in a trip of its own instead of a walk inside the light loop (STRICT). Same draws in the same order, same arithmetic: the
@@ -171,12 +171,13 @@ def test_one_light_kernel_equals_the_general_one(scenes, strict):
         assert sc.n_lights == 1, key
         got = {}
         for flags in (0, capi.KAJO_FLAG_NO_ONE_LIGHT, capi.KAJO_FLAG_NO_ONE_LIGHT | capi.KAJO_FLAG_NO_SPLIT, capi.KAJO_FLAG_NO_SPLIT):
-            with HipRenderer(sc, W, H, spp=S, seed=SEED, depth_limit=depth, strict=strict, counters=True, flags=flags, passes_per_launch=ppl) as r:
+            with HipRenderer(sc, W, H, spp=S, seed=SEED, depth_limit=depth, strict=(numerics == "strict"), exact=(numerics == "exact"), counters=True,
+                             flags=flags, passes_per_launch=ppl) as r:
                 got[flags] = (r.render(passes).radiance(), r.counters())
         walks = lambda c: c["traversals"] + c["shadowQueries"]
         for flags in got:
-            assert bits_equal(got[0][0], got[flags][0]), (key, strict, flags)
-            assert walks(got[0][1]) == walks(got[flags][1]) and got[0][1]["vertices"] == got[flags][1]["vertices"], (key, strict, flags, got[0][1], got[flags][1])
+            assert bits_equal(got[0][0], got[flags][0]), (key, numerics, flags)
+            assert walks(got[0][1]) == walks(got[flags][1]) and got[0][1]["vertices"] == got[flags][1]["vertices"], (key, numerics, flags, got[0][1], got[flags][1])
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4])

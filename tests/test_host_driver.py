@@ -115,6 +115,20 @@ def test_three_argument_constructor_takes_the_whole_node(tmp_path, scenes):
     assert p.returncode == 2 and "KAJO_HIP_NUMERICS" in p.stderr
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=dict(env, KAJO_HIP_GPUS="1"))
     assert p.returncode == 0 and json.loads(p.stdout.strip().splitlines()[-1])["gpus"] == 1
+    # The form's MULTI-GPU code -- ncclCommInitAll, grouped send / receive, the image resolved from the gathered tile buffers, host copy --
+    # run here with one owner sending to itself (round-4 advisor finding: on a one-GPU box the default took the no-gather shortcut, so
+    # the path a node runs had never executed through this constructor). Same frame, same image.
+    out2, raw2 = str(tmp_path / "g.png"), str(tmp_path / "g.raw")
+    cmd2 = [c if c not in (out, raw) else (out2 if c == out else raw2) for c in cmd]
+    p = subprocess.run(cmd2, capture_output=True, text=True, timeout=180, env=dict(env, KAJO_HIP_FORCE_GATHER="1"))
+    assert p.returncode == 0, p.stderr
+    st2 = json.loads(p.stdout.strip().splitlines()[-1])
+    with HipRenderer(sc, 160, 90, exact=True) as r:
+        want2 = r.render(st2["passes"]).radiance()
+        px2 = r.argb8()
+    assert np.array_equal(np.fromfile(raw2, np.float32).reshape(90, 160, 4).view(np.uint32), want2.view(np.uint32))
+    png = read_png(out2)
+    assert np.array_equal(png[..., 0], (px2 >> 16) & 255) and np.array_equal(png[..., 1], (px2 >> 8) & 255) and np.array_equal(png[..., 2], px2 & 255)
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=180, env=dict(env, KAJO_HIP_GPUS=str(torch.cuda.device_count() + 1)))
     assert p.returncode == 2 and "KAJO_HIP_GPUS" in p.stderr
 
@@ -151,3 +165,54 @@ def test_unknown_renderer_and_bad_scene(tmp_path):
     bad.write_text("[]")
     p = subprocess.run([BIN, str(bad)], capture_output=True, text=True)
     assert p.returncode == 1 and "Failed to parse scene" in p.stderr  # renderer/Main.cpp:126-129
+
+
+def test_window_closed_mid_run(tmp_path, scenes):
+    """The reference's only stopping condition is its window (renderer/cpu/Scheduler.cpp:74: `while (preview->processEvents())`,
+    Esc in renderer/Preview.cpp:216-234), and it shows every pass as it completes (Preview::update, :79-98, on the main thread: SDL).
+    The headless stand-in closes at its K-th processEvents() call, mid-run, whatever the pass count is then: hip::Scheduler::run()
+    must return without starting another launch (it overshoots by at most the launch in flight: one batch), must have called
+    update() for every pass, in order, on the calling thread, and Image::pixels must hold the frame of the passes it reported."""
+    sc = scenes["spheres_a169"]
+    pod = str(tmp_path / "scene.pod")
+    sc.write_pod(pod)
+    out, raw = str(tmp_path / "o.png"), str(tmp_path / "o.raw")
+    # no pass budget (--passes 0: until the window closes), batches of 3 passes, the window closes at the 5th look at the event queue
+    cmd = [BIN, "-w", "160", "-h", "90", "-r", "hip", "--passes", "0", "--batch", "3", "--close-at-event", "5", "--gpus", "1", "-o", out, "--raw", raw,
+           "--json", "--scene-pod", pod]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, p.stderr
+    st = json.loads(p.stdout.strip().splitlines()[-1])
+    assert st["preview_event_calls"] == 5           # asked once per batch, before it; the fifth answer ended the loop
+    assert st["batch_passes"] == [3, 3, 3, 3] and st["passes"] == 12
+    assert st["preview_updates"] == list(range(1, 13)) and st["preview_updates_on_owning_thread"] is True
+    with HipRenderer(sc, 160, 90, exact=True) as r:
+        want = r.render(12).radiance()
+        px = r.argb8()
+    assert np.array_equal(np.fromfile(raw, np.float32).reshape(90, 160, 4).view(np.uint32), want.view(np.uint32))
+    png = read_png(out)  # Image::pixels as run() left it: the last resolved frame, all 12 passes
+    assert np.array_equal(png[..., 0], (px >> 16) & 255) and np.array_equal(png[..., 1], (px >> 8) & 255) and np.array_equal(png[..., 2], px & 255)
+    # the automatic batch (no --batch): a window that is open gets a refresh per ~33 ms, never a launch of more than 16 passes
+    cmd = [BIN, "-w", "160", "-h", "90", "-r", "hip", "--passes", "0", "--close-at-event", "4", "--gpus", "1", "-o", "", "--json", "--scene-pod", pod]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, p.stderr
+    st = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(st["batch_passes"]) == 3 and st["batch_passes"][0] == 1 and max(st["batch_passes"]) <= 16
+    assert st["preview_updates"] == list(range(1, st["passes"] + 1))
+
+
+def test_headless_launches_of_a_large_scene_are_bounded(tmp_path, scenes):
+    """A launch cannot be interrupted, so its length bounds how late run() notices anything. Round 4 launched 16 passes at a time
+    without a preview whatever they cost (the 1000-sphere scene at 4K: 0.6 s per launch). Now the batch follows the measured time
+    per pass toward half a second: after the first (two-pass) launch no launch of this run is planned longer than that."""
+    from kajo_amd.scene import stress_scene
+    sc = stress_scene(scenes["spheres_a169"], 1000, 16)
+    pod = str(tmp_path / "scene.pod")
+    sc.write_pod(pod)
+    cmd = [BIN, "-w", "2560", "-h", "1440", "-r", "hip", "--passes", "40", "--gpus", "1", "-o", "", "--json", "--scene-pod", pod, "--fast"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    st = json.loads(p.stdout.strip().splitlines()[-1])
+    assert st["passes"] == 40 and st["batch_passes"][0] == 2 and sum(st["batch_passes"]) == 40
+    assert max(st["batch_ms"][1:]) < 900.0, st["batch_ms"]   # planned for <= 500 ms from the running estimate
+    assert max(st["batch_passes"]) < 40

@@ -25,6 +25,7 @@ int main(int argc, char** argv)
     std::string podPath;
     bool verbose = false, json = false, threeArg = false;
     int closeAtEvent = 0;
+    bool noPreview = false;
     for (size_t i = 1; i < args.size(); i++) {
         bool more = i + 1 < args.size();
         const std::string& a = args[i];
@@ -50,6 +51,8 @@ int main(int argc, char** argv)
                         "    --same-device   put every tile owner on GPU 0 (testing; implies --gather copy)\n"
                         "    --force-gather  run the gather + compose step with one GPU too (testing: the RCCL call sequence at N = 1)\n"
                         "    --close-at-event K  the headless preview's window closes at the K-th processEvents() call (testing: Esc mid-run)\n"
+                        "    --no-preview    hand the backend a null Preview* (what renderer/Main.cpp:132 gets without a display): run() renders\n"
+                        "                    --passes passes (16 when 0) in launches planned for half a second at most\n"
                         "    -o FILE         PNG output (out.png)\n"
                         "    --raw FILE      also dump the float4 accumulation (W*H*4 floats)\n"
                         "    --json          print run statistics as one JSON line\n"
@@ -73,6 +76,7 @@ int main(int argc, char** argv)
         else if (a == "--force-gather") opt.forceGather = true;
         else if (a == "--three-arg") threeArg = true;
         else if (a == "--close-at-event" && more) closeAtEvent = std::atoi(args[++i].c_str());
+        else if (a == "--no-preview") noPreview = true;
         else if (a == "--scene-pod" && more) podPath = args[++i];
         else if (a == "-o" && more) out = args[++i];
         else if (a == "--raw" && more) rawOut = args[++i];
@@ -124,7 +128,8 @@ int main(int argc, char** argv)
     try {
         if (rendererName == "hip") {
             // (--three-arg: the statement integration/apply_to_kajo.sh adds to renderer/Main.cpp:135-142, word for word)
-            hipScheduler = threeArg ? new hip::Scheduler(scene, image.get(), preview.get()) : new hip::Scheduler(scene, image.get(), preview.get(), opt);
+            Preview* pv = noPreview ? nullptr : preview.get();
+            hipScheduler = threeArg ? new hip::Scheduler(scene, image.get(), pv) : new hip::Scheduler(scene, image.get(), pv, opt);
             scheduler.reset(hipScheduler);
         } else {
             std::cerr << "Unknown renderer: " << rendererName << std::endl;

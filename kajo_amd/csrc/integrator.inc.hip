@@ -575,6 +575,43 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
         return Hit{best, tMax, tMax};
     }
 #endif
+#if KAJO_STRICT && !KAJO_IEEE_BY_COMPILER
+    if (sc.allTranslated) {
+        // Every sphere a (centre, radius) record (all of the reference's data/ scenes): the loop of sphereCandidate's translated branch
+        // with what does not depend on the sphere taken out of it -- a = d.d, -4a, and the refined reciprocal of a that kdiv(q, a)
+        // forms (the same v_rcp and two FMAs on the same operand: the same value) -- and no branch on the record's kind per
+        // sphere. Same operations on the same operands in the same order: the same bits (every STRICT = oracle test runs through here).
+        const float m4a = -4.0f * aT; // b^2 - (4a)c == b^2 + (-(4a))c: negation is exact
+        float y = __builtin_amdgcn_rcpf(aT);
+        y = __builtin_fmaf(__builtin_fmaf(-aT, y, 1.0f), y, y);
+        for (int i = 0; i < ns; i++) { // Raytracer.cpp:21-72
+            const DFloat4 s = lds.sphereHot[i];
+            const F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
+            const float h = dot(d, o);
+            const float c = dot(o, o) - s.w;
+            const float b = 2 * h;
+            const float discr = b * b + m4a * c;
+            if (__builtin_amdgcn_ballot_w64(!(discr < 0.0f)) == 0ull) // (no ray of the wave reaches this sphere's line: see sphereCandidate)
+                continue;
+            const float sq = ksqrt(discr);
+            const float q = (b < 0.0f) ? (-b - sq) * .5f : (-b + sq) * .5f;
+            float t0 = q * y; // q / a, kdiv's sequence on the shared reciprocal
+            float r = __builtin_fmaf(-aT, t0, q);
+            t0 = __builtin_fmaf(r, y, t0);
+            r = __builtin_fmaf(-aT, t0, q);
+            t0 = __builtin_amdgcn_div_fixupf(__builtin_fmaf(r, y, t0), aT, q);
+            const float t1 = kdiv(c, q);
+            const bool sw = t0 > t1;
+            const float lo = sw ? t1 : t0, hi = sw ? t0 : t1;
+            const float th = (lo < 0.0f) ? hi : lo; // (* determinant: exactly 1)
+            const bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(th > tMax || th < 0.0f);
+            tMax = ok ? th : tMax;
+            best = ok ? np + 1 + i : best;
+            bestT0 = ok ? th : bestT0;
+        }
+        return Hit{best, tMax, bestT0};
+    }
+#endif
     for (int i = 0; i < ns; i++) { // Raytracer.cpp:21-72
         float ts, th;
         bool ok = sphereCandidate(sc, lds, i, O, d, aT, iaT, ts, th) && !(ts > tMax || ts < 0.0f);

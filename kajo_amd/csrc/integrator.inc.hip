@@ -498,6 +498,24 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
         tMax = __builtin_bit_cast(float, kMax);
     } else
 #endif
+#if KAJO_STRICT
+    if (sc.planesRigid) {
+        // Every determinant within 2^-20 of 1 (all of the reference's data/ scenes: rotations and translations): t * det has the sign
+        // of t -- a positive factor cannot make a product negative, and -0 stays -0, which `< 0` does not hold for either -- so
+        // Raytracer.cpp:115's `t < ray.min` repeats :85-86's `t < 0` and is not asked again. The same t, the same t * det.
+        for (int i = 0; i < np; i++) {
+            const DFloat4 r = lds.planeRow[i];
+            const float det = lds.planeDet[i];
+            float denom = r.x * d.x + r.y * d.y + r.z * d.z;
+            float oy = r.x * O.x + r.y * O.y + r.z * O.z + r.w * 1.0f;
+            float t = kdiv(-oy, denom);
+            float ts = t * det;
+            bool ok = !(__builtin_fabsf(denom) < kFltEpsilon) && !(t < 0.0f) && !(ts > tMax);
+            tMax = ok ? ts : tMax;
+            best = ok ? i + 1 : best;
+        }
+    } else
+#endif
     for (int i = 0; i < np; i++) { // Raytracer.cpp:74-98; only row y of the inverse matters
         const DFloat4 r = lds.planeRow[i];
         const float det = lds.planeDet[i];
@@ -604,7 +622,9 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
             const bool sw = t0 > t1;
             const float lo = sw ? t1 : t0, hi = sw ? t0 : t1;
             const float th = (lo < 0.0f) ? hi : lo; // (* determinant: exactly 1)
-            const bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(th > tMax || th < 0.0f);
+            // (Raytracer.cpp:115's `t < ray.min` asks nothing new here: th is lo unless lo is negative, and then it is hi, which the test
+            // before it found not negative; a NaN answers false to all of them either way)
+            const bool ok = !(discr < 0.0f) && !(hi < 0.0f) && !(th > tMax);
             tMax = ok ? th : tMax;
             best = ok ? np + 1 + i : best;
             bestT0 = ok ? th : bestT0;

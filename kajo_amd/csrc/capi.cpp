@@ -439,14 +439,20 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         v.grid.reach2 = st.gridReach2;
     }
     {
-        const uint32_t* start = nullptr;
-        const DShadowItem* items = nullptr;
-        CREATE_TRY(upload(st.shadowStart, &start, h->sceneBuffers));
-        CREATE_TRY(upload(st.shadowItems, &items, h->sceneBuffers));
+        const uint32_t* rowBase = nullptr;
+        const uint16_t* off16 = nullptr;
+        const uint32_t* items = nullptr;
+        const float* invKeyScale = nullptr;
+        CREATE_TRY(upload(st.shadowRowBase, &rowBase, h->sceneBuffers));
+        CREATE_TRY(upload(st.shadowOff16, &off16, h->sceneBuffers));
+        CREATE_TRY(upload(st.shadowPacked, &items, h->sceneBuffers));
+        CREATE_TRY(upload(st.shadowInvKeyScale, &invKeyScale, h->sceneBuffers));
         v.shadow.enabled = st.shadowEnabled ? 1 : 0;
         v.shadow.n = st.shadowN;
-        v.shadow.start = start;
+        v.shadow.rowBase = rowBase;
+        v.shadow.off16 = off16;
         v.shadow.items = items;
+        v.shadow.invKeyScale = invKeyScale;
     }
     v.nPlanes = st.nPlanes;
     v.nSpheres = st.nSpheres;

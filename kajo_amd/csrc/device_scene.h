@@ -101,18 +101,29 @@ struct DGrid
 // per-sphere arithmetic as the closest-hit walk on the light, the planes and the bin's spheres nearer than O, and applies the
 // walk's acceptance rule in its order-independent form (closest wins; among equal distances the later object): the answer is
 // the brute-force walk's, from a handful of tests instead of a grid walk.
-struct DShadowItem
+struct DShadowItem // host side (stage.cpp builds and sorts these; tests read them through kajo_hip_stage_shadow_lists)
 {
     float key;      // |c_i - C| - (radius_i + margin): no point of the ray nearer to C than this can touch sphere i
     uint32_t index; // sphere index
 };
 
+// What the kernels read (round 5: 3.4 MB for 1000 spheres / 16 lights where the 8-byte items and 32-bit starts of round 4 took
+// 6.8 MB -- more than one XCD's 4 MB of L2, so every list read missed it):
+//   items    one 32-bit word per item: the key in 16 bits -- in units of the light's `keyScale`, ROUNDED DOWN, so a quantised key
+//            never exceeds the true bound and the walk can only test more items, never fewer -- over the sphere index in 16
+//            (a scene with a grid has at most 65 535 spheres); ascending key within a bin
+//   rowBase  [nLights * 6 * n] first item of every row of bins (32 bits)
+//   off16    [nLights * 6 * n][n + 1] first item of every bin relative to its row's base, and the row's end (16 bits: a row of 64 bins
+//            holds a few hundred items; staging gives up on the lists if one ever exceeded 65 535)
+// 1 / keyScale of light k rides in the w of its emission record in LDS (LdsScene::lightEmission).
 struct DShadowLists
 {
     int32_t enabled;
     int32_t n;                 // bins per cube-face axis
-    const uint32_t* start;     // [nLights * 6 * n * n + 1]
-    const DShadowItem* items;  // ascending key within a bin
+    const uint32_t* rowBase;
+    const uint16_t* off16;
+    const uint32_t* items;
+    const float* invKeyScale;  // [nLights]
 };
 
 struct DSceneView // device pointers + counts, passed to the kernels by value

@@ -252,7 +252,27 @@ struct LdsScene
     // every cell record and every item (profiles/r03_c5_notes.txt).
     const uint32_t* gridCellStartLds;
     const uint16_t* gridItemsLds;
+#ifdef KAJO_PROFILE
+    unsigned long long* testCounter; // diagnostic twin: [0] sphere tests of the grid walks, [1] of the list walks, [2] light-sphere tests of the queries (lane counts)
+#endif
 };
+
+// Diagnostic twin only: how many sphere tests the LANES of this wave are about to run (the algorithmic work of a culled walk is what
+// each ray's own walk tests, profiles/r05_c5_roofline.json) -- one atomic per wave and loop round, by its first active lane.
+#ifdef KAJO_PROFILE
+#define KAJO_COUNT_TESTS(lds, which)                                                                                   \
+    do {                                                                                                               \
+        if ((lds).testCounter) {                                                                                       \
+            const unsigned long long m_ = __ballot(true);                                                              \
+            if ((int)(threadIdx.x & 63) == __builtin_ctzll(m_))                                                        \
+                atomicAdd((lds).testCounter + (which), (unsigned long long)__builtin_popcountll(m_));                  \
+        }                                                                                                              \
+    } while (0)
+#else
+#define KAJO_COUNT_TESTS(lds, which)                                                                                   \
+    do {                                                                                                               \
+    } while (0)
+#endif
 
 // One sphere of Raytracer.cpp:21-72 up to (not including) processIntersection: returns false when the
 // reference returns early (discriminant < 0, or both roots behind the origin); otherwise th = the
@@ -390,6 +410,7 @@ KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* 
             uint32_t nidBase = ~(uint32_t)(np + 1);
             asm volatile("" : "+v"(nidBase)); // (one v_sub per item: left to itself the compiler re-derives -(np + i) - 2 in three)
             for (uint32_t k = k0; k < e; k++) {
+                KAJO_COUNT_TESTS(lds, 0);
                 const int i = (int)gridItems[k];
                 const DFloat4 s = lds.sphereHot[i];
                 F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
@@ -407,6 +428,7 @@ KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* 
         } else
 #endif
         for (uint32_t k = k0; k < e; k++) {
+            KAJO_COUNT_TESTS(lds, 0);
             const int i = (int)gridItems[k];
             float ts, th;
             const bool valid = sphereCandidate(sc, lds, i, O, d, aT, iaT, ts, th);
@@ -734,8 +756,9 @@ KDEV bool shadowItemBlocks(const DSceneView& sc, const LdsScene& lds, int i, int
 #endif
 }
 
-// The bin of the light's cube map that u = O - C falls into, and how far from the light's centre the ray reaches.
-KDEV uint32_t shadowBin(const DSceneView& sc, const DSphereCold& lc, int lightK, F3 O, float& reach)
+// The bin of the light's cube map that u = O - C falls into -- as (row of bins, bin in the row): DShadowLists -- and how far from the
+// light's centre the ray reaches, in the units of the light's quantised keys, rounded UP.
+KDEV uint32_t shadowBin(const DSceneView& sc, const DSphereCold& lc, int lightK, float invKeyScale, F3 O, uint32_t& binInRow, uint32_t& reachQ)
 {
     const F3 u = f3(O.x - lc.cx, O.y - lc.cy, O.z - lc.cz);
     const float ax = __builtin_fabsf(u.x), ay = __builtin_fabsf(u.y), az = __builtin_fabsf(u.z);
@@ -752,8 +775,11 @@ KDEV uint32_t shadowBin(const DSceneView& sc, const DSphereCold& lc, int lightK,
     ia = min(max(ia, 0), N - 1);
     ib = min(max(ib, 0), N - 1);
     const int face = 2 * m + (um < 0.0f ? 1 : 0);
-    reach = fmaxf(ksqrt(dot(u, u)), lc.radius) * 1.000001f;
-    return (uint32_t)((((lightK * 6 + face) * N) + ib) * N + ia);
+    const float reach = fmaxf(__builtin_amdgcn_sqrtf(dot(u, u)), lc.radius) * 1.000002f; // (hardware root, 1 ulp, inside the factor)
+    // an item is left out of the walk only if its quantised key -- a lower bound of its true key -- exceeds this: floor(x) + 1 > x
+    reachQ = (uint32_t)fminf(reach * invKeyScale * 1.000001f, 65534.0f) + 1u;
+    binInRow = (uint32_t)ia;
+    return (uint32_t)(((lightK * 6 + face) * N) + ib);
 }
 
 // ---- surface point of an accepted hit ------------------------------------------------------
@@ -1066,6 +1092,9 @@ enum : int
 #ifndef KAJO_INLINE_SHADOW
 #define KAJO_INLINE_SHADOW 0
 #endif
+#ifndef KAJO_LISTS_TILE_RMW
+#define KAJO_LISTS_TILE_RMW 0
+#endif
 #if KAJO_STRICT
 #define KAJO_IS_A_NUMBER(x) ((x) == (x))
 #else
@@ -1099,6 +1128,9 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     stage16(ldsPlaneRow, sc.planeRow, np);
     stage16(ldsSphereHot, sc.sphereHot, sc.nSphereHot);
     LdsScene lds;
+#ifdef KAJO_PROFILE
+    lds.testCounter = nullptr;
+#endif
     lds.planeRow = ldsPlaneRow;
     lds.sphereHot = ldsSphereHot;
     if (COLD_LDS) {
@@ -1138,7 +1170,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
         lc4[i] = reinterpret_cast<const DFloat4*>(sc.sphereCold + sc.light[i >> 2])[i & 3];
     for (int i = threadIdx.x; i < sc.nLights; i += blockDim.x) {
         const DMaterial& lm = sc.material[np + sc.light[i]];
-        le4[i] = DFloat4{lm.emission[0], lm.emission[1], lm.emission[2], 0.0f};
+        le4[i] = DFloat4{lm.emission[0], lm.emission[1], lm.emission[2], (!COLD_LDS && sc.shadow.enabled) ? sc.shadow.invKeyScale[i] : 0.0f};
     }
     // per (light, plane): which side of the plane the light's ball is on (lightReached skips planes the ray cannot cross)
     // (read by the large-scene kernels only; the space is reserved in every layout so that capi.cpp has one size formula)
@@ -1209,7 +1241,12 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     const int np = sc.nPlanes;
 
     // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
+#ifdef KAJO_PROFILE
+    LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
+    lds.testCounter = args.counters ? args.counters + 29 : nullptr;
+#else
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
+#endif
     if (threadIdx.x == 0) { // what only the camera-ray block needs of the launch: kept out of the scalar registers
         DFloat4* cam = const_cast<DFloat4*>(lds.camera);
         cam[5] = DFloat4{args.pixelWidth, args.pixelHeight, args.sampleWidth, args.sampleHeight};
@@ -1251,7 +1288,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // (the handle zeroes the buffer when it is created or reset)
     F3 total = f3(0.0f, 0.0f, 0.0f);
     float totalW = 0.0f;
-    if (!KAT && !LISTS && inImage) {
+    // (LISTS_RMW: the large-scene list kernels of rounds 3-4 -- 128 VGPRs and spilling -- did not carry the pixel's total through the loop:
+    // a pass end added its term to the tile buffer in place, 32 bytes of traffic per pixel and PASS instead of per launch)
+    constexpr bool LISTS_RMW = LISTS && KAJO_LISTS_TILE_RMW;
+    if (!KAT && !LISTS_RMW && inImage) {
         const float4 t = reinterpret_cast<const float4*>(args.tiles)[slot];
         total = f3(t.x, t.y, t.z);
         totalW = t.w;
@@ -1404,7 +1444,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     mailbox[stolenFrom * stealWindow + (pass - stealBase)] = DFloat4{term.x, term.y, term.z, 0.0f};
                     stolenFrom = -1;
                 } else {
-                    if (LISTS) {
+                    if (LISTS_RMW) {
                         float4* acc = reinterpret_cast<float4*>(args.tiles) + slot;
                         const float4 t4 = *acc;
                         *acc = make_float4(t4.x + term.x, t4.y + term.y, t4.z + term.z, t4.w);
@@ -1683,7 +1723,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             // looked: +1.4 % FAST, +0.9 % STRICT on the 1000-sphere scene.)
             KajoLdsWord* helpOwner = (KajoLdsWord*)(reinterpret_cast<unsigned char*>(mailbox) + 64 * stealWindow * 16);
             KajoLdsWord* helpFlag = helpOwner + 64;
-            const uint2* items = reinterpret_cast<const uint2*>(sc.shadow.items);
+            const uint32_t* items = sc.shadow.items;
             const int nL = sc.nLights;
             const bool canHelp = sampleNext || pathDone || mode == MODE_DONE; // (their O / d are rewritten before they are read again)
             int k = sampleNext ? lightK : nL;
@@ -1691,7 +1731,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 bool hasQ = false;
                 uint32_t keyL = 0, k0 = 0, e = 0;
                 int si = 0;
-                float reach = 0.0f;
+                uint32_t reachQ = 0;
                 if (k < nL) {
                     // Lights whose sample is discarded whatever it is only draw their random number (see the loop further down)
                     for (; k < nL; k++) {
@@ -1732,11 +1772,15 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                             const DFloat4 le = lds.lightEmission[k];
                             pendContrib = ((rrcp(pb + pl) * fl) * cosL) * f3(le.x, le.y, le.z);
                             ctrShadow += 1;
+                            KAJO_COUNT_TESTS(lds, 2);
                             hasQ = lightReachedHead(sc, lds, k, si, O, d, keyL);
                             if (hasQ) {
-                                const uint32_t bin = shadowBin(sc, lc, k, O, reach);
-                                k0 = sc.shadow.start[bin];
-                                e = sc.shadow.start[bin + 1];
+                                uint32_t ia;
+                                const uint32_t row = shadowBin(sc, lc, k, le.w, O, ia, reachQ);
+                                const uint16_t* off = sc.shadow.off16 + row * (uint32_t)(sc.shadow.n + 1) + ia;
+                                const uint32_t base = sc.shadow.rowBase[row];
+                                k0 = base + off[0];
+                                e = base + off[1];
                             }
                         }
                         k++;
@@ -1781,7 +1825,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     KAJO_FROM_OWNER_U(k0);
                     KAJO_FROM_OWNER_U(e);
                     si = (int)__builtin_amdgcn_ds_bpermute(addr, si);
-                    KAJO_FROM_OWNER_F(reach);
+                    KAJO_FROM_OWNER_U(reachQ);
 #undef KAJO_FROM_OWNER_F
 #undef KAJO_FROM_OWNER_U
                     bool blocked = false;
@@ -1793,20 +1837,21 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #else
                         const float iaT = krcp(aT);
 #endif
-                        // (key, index) pairs, 8 bytes each, the next one requested before the current one is tested; sorted by key
+                        // (quantised key << 16 | sphere index), 4 bytes each, the next one requested before the current one is tested; sorted by key
                         const uint32_t stride = (uint32_t)G + 1u;
                         uint32_t j = k0 + (uint32_t)sub;
-                        uint2 nxt = make_uint2(0x7f800000u, 0u);
+                        uint32_t nxt = 0xffffffffu;
                         if (j < e)
                             nxt = items[j];
                         while (j < e) {
-                            const uint2 cur = nxt;
+                            const uint32_t cur = nxt;
                             j += stride;
                             if (j < e)
                                 nxt = items[j];
-                            if (__builtin_bit_cast(float, cur.x) > reach) // nothing further along the list can touch the ray before it ends
+                            if ((cur >> 16) > reachQ) // nothing further along the list can touch the ray before it ends
                                 break;
-                            if (shadowItemBlocks(sc, lds, (int)cur.y, si, O, d, aT, iaT, keyL)) {
+                            KAJO_COUNT_TESTS(lds, 1);
+                            if (shadowItemBlocks(sc, lds, (int)(cur & 0xffffu), si, O, d, aT, iaT, keyL)) {
                                 blocked = true;
                                 break;
                             }
@@ -2040,7 +2085,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
         }
     } else if (!KAT && inImage) {
-        if (LISTS) { // (the own passes' terms are in the buffer already)
+        if (LISTS_RMW) { // (the own passes' terms are in the buffer already)
             const float4 t4 = reinterpret_cast<const float4*>(args.tiles)[slot];
             total = f3(t4.x, t4.y, t4.z);
             totalW = t4.w;

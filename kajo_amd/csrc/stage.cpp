@@ -595,6 +595,39 @@ void buildShadowLists(const KajoScene& s, StagedScene& out, bool wanted)
     }
     out.shadowStart[lists.size()] = (uint32_t)out.shadowItems.size();
     out.shadowN = N;
+    // The kernels' form (device_scene.h DShadowLists): 16-bit keys in units of a per-light scale, rounded DOWN (a key only bounds from
+    // below where a sphere can first be touched: a smaller key keeps the item in more walks, never drops it from one) and re-sorted
+    // stably by the quantised key; 16-bit bin starts relative to a 32-bit base per row of bins.
+    out.shadowInvKeyScale.assign(nL, 1.f);
+    out.shadowPacked.assign(out.shadowItems.size(), 0u);
+    out.shadowRowBase.assign((size_t)nL * 6 * N, 0u);
+    out.shadowOff16.assign((size_t)nL * 6 * N * (N + 1), 0);
+    for (int L = 0; L < nL; L++) {
+        float maxKey = 0.f;
+        for (size_t j = out.shadowStart[(size_t)L * binsPerLight]; j < out.shadowStart[(size_t)(L + 1) * binsPerLight]; j++)
+            maxKey = std::fmax(maxKey, out.shadowItems[j].key);
+        const double scale = std::fmax((double)maxKey, 1e-6) / 65535.0 * (1 + 1e-6);
+        out.shadowInvKeyScale[L] = (float)(1.0 / scale);
+        for (size_t row = (size_t)L * 6 * N; row < (size_t)(L + 1) * 6 * N; row++) {
+            const size_t b0 = row * N;
+            const uint32_t base = out.shadowStart[b0];
+            if (out.shadowStart[b0 + N] - base > 65535u)
+                return; // (a row of bins with more than 65 535 items: no lists for this scene)
+            out.shadowRowBase[row] = base;
+            for (int ia = 0; ia <= N; ia++)
+                out.shadowOff16[row * (N + 1) + ia] = (uint16_t)(out.shadowStart[b0 + ia] - base);
+            for (int ia = 0; ia < N; ia++) {
+                const uint32_t a = out.shadowStart[b0 + ia], e = out.shadowStart[b0 + ia + 1];
+                for (uint32_t j = a; j < e; j++) { // (ascending float keys quantise to ascending integers: the order stands)
+                    const DShadowItem& it = out.shadowItems[j];
+                    double q = std::floor((double)std::fmax(it.key, 0.f) / scale);
+                    q = q > 65535.0 ? 65535.0 : q;
+                    out.shadowPacked[j] = ((uint32_t)q << 16) | (it.index & 0xffffu);
+                    out.shadowItems[j].key = (float)(q * scale * (1 - 1e-6)); // what the kernel's comparison amounts to (never above the true key)
+                }
+            }
+        }
+    }
     out.shadowEnabled = true;
 }
 

@@ -38,8 +38,12 @@ struct StagedScene
     // world-space ball)
     bool shadowEnabled = false;
     int shadowN = 0;
-    std::vector<uint32_t> shadowStart;
-    std::vector<DShadowItem> shadowItems;
+    std::vector<uint32_t> shadowStart;     // [bins + 1], 32-bit, and
+    std::vector<DShadowItem> shadowItems;  // float keys: the lists as built (host side: tests, kajo_hip_stage_shadow_lists)
+    // ... and as the kernels read them (device_scene.h DShadowLists)
+    std::vector<uint32_t> shadowPacked, shadowRowBase;
+    std::vector<uint16_t> shadowOff16;
+    std::vector<float> shadowInvKeyScale;
 };
 
 void stageScene(const KajoScene& scene, StagedScene& out, int gridMinSpheres = 48, bool shadowLists = true);

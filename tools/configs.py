@@ -20,13 +20,14 @@ cases=[('C1 256x256 S=16 depth1 1 pass',a1,256,256,16,1,1),
        ('C5 4K 32xS32 (all of its 1024 spp, 32 passes per launch)',stress_scene(a169,1000,16),3840,2160,32,32,8)]
 sel=sys.argv[1:] 
 strict = 'strict' in sel
+exact = 'exact' in sel
 nolists = 'nolists' in sel   # large scenes: shadow rays through the grid (round 3's schedule) instead of the lights' visibility lists
-sel = [x for x in sel if x not in ('strict', 'nolists')]
+sel = [x for x in sel if x not in ('strict', 'exact', 'nolists')]
 FLAGS = 128 if nolists else 0
 for name,sc,W,H,S,passes,depth in cases:
     if sel and not any(s in name for s in sel): continue
     # rate: a handle WITHOUT device counters (their per-wave atomics weigh on launches of many short waves), several launches back to back
-    with HipRenderer(sc,W,H,spp=S,depth_limit=depth,strict=strict,passes_per_launch=passes,flags=FLAGS) as r:
+    with HipRenderer(sc,W,H,spp=S,depth_limit=depth,strict=strict,exact=exact,passes_per_launch=passes,flags=FLAGS) as r:
         r.render(passes).wait(); r.render(passes).wait()          # warm (the first launch also records the launch order)
         reps = 20 if W*H*passes < 4e6 else (3 if W*H*passes < 2e8 else 1)
         c0=r.counters(); t=time.perf_counter()
@@ -34,7 +35,7 @@ for name,sc,W,H,S,passes,depth in cases:
         r.wait(); dt=(time.perf_counter()-t)/reps; c1=r.counters()
     ms=(c1['kernelMs']-c0['kernelMs'])/reps
     # work per path: a handle with counters
-    with HipRenderer(sc,W,H,spp=S,depth_limit=depth,strict=strict,counters=True,passes_per_launch=passes,flags=FLAGS) as r:
+    with HipRenderer(sc,W,H,spp=S,depth_limit=depth,strict=strict,exact=exact,counters=True,passes_per_launch=passes,flags=FLAGS) as r:
         c=r.render(passes).counters()
     paths=c['paths']
     print('%-48s %8.1f Mpaths/s wall, kernel %8.3f ms, %5.2f trav/path (+ %4.2f shadow queries from light lists), %5.2f vert/path, lane eff %.3f'%(

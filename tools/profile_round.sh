@@ -33,7 +33,8 @@ for k, d in a.items():
     d["collected"] = "round ${R}, MI355X, rocprofv3 --kernel-trace --pmc (six separate passes, tools/pmc.sh) over python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline" + (" --strict" if "strict" in k else " --fast" if "fast" in k else "")
 json.dump(a, open("$OUT/counters.json", "w"), indent=1, sort_keys=True)
 PY
-python3 tools/configs.py > $OUT/configs.txt 2>&1
+(echo "== EXACT"; python3 tools/configs.py exact; echo "== FAST"; python3 tools/configs.py; echo "== STRICT"; python3 tools/configs.py strict) > $OUT/configs.txt 2>&1
+python3 tools/configs_roofline.py $OUT/configs_roofline.json > $OUT/configs_roofline.txt 2>&1
 echo "configs done"
 python3 tools/blockprof.py exact spheres > $OUT/blockprof_exact.txt 2>&1
 python3 tools/blockprof.py fast spheres > $OUT/blockprof_fast.txt 2>&1

@@ -16,8 +16,10 @@ NO_SPLIT = capi.KAJO_FLAG_NO_SPLIT if "--no-split" in sys.argv else 0
 SIZES = ((64, 36), (128, 72), (256, 144), (512, 288), (640, 360), (640, 480), (800, 600), (960, 540), (1280, 720), (1920, 1080), (2560, 1440), (3840, 2160), (7680, 4320))
 if "--small" in sys.argv:
     SIZES = ((256, 144), (512, 288), (640, 360), (640, 480), (800, 600), (960, 540), (1280, 720), (1600, 900), (1920, 1080))
+MODE = "fast" if "fast" in sys.argv else ("strict" if "strict" in sys.argv else "exact")  # default: the build bench.py times
+print("numerics", MODE, flush=True)
 for (w, h) in SIZES:
-    with HipRenderer(sc, w, h, counters=True, flags=NO_SPLIT) as r:
+    with HipRenderer(sc, w, h, counters=True, flags=NO_SPLIT, strict=(MODE == "strict"), exact=(MODE == "exact")) as r:
         r.render(16).wait()  # records the trip counts the launch order uses
         c0 = r.counters()
         n = 3

@@ -252,14 +252,15 @@ struct LdsScene
     // every cell record and every item (profiles/r03_c5_notes.txt).
     const uint32_t* gridCellStartLds;
     const uint16_t* gridItemsLds;
-#ifdef KAJO_PROFILE
+#ifdef KAJO_COUNT_SPHERE_TESTS
     unsigned long long* testCounter; // diagnostic twin: [0] sphere tests of the grid walks, [1] of the list walks, [2] light-sphere tests of the queries (lane counts)
 #endif
 };
 
-// Diagnostic twin only: how many sphere tests the LANES of this wave are about to run (the algorithmic work of a culled walk is what
-// each ray's own walk tests, profiles/r05_c5_roofline.json) -- one atomic per wave and loop round, by its first active lane.
-#ifdef KAJO_PROFILE
+// Counting twin only (`make -C kajo_amd/csrc count`: -DKAJO_COUNT_SPHERE_TESTS; its atomics distort every timing): how many sphere
+// tests the LANES of this wave are about to run -- the algorithmic work of a culled walk is what each ray's own walk tests
+// (tools/configs_roofline.py) -- one atomic per wave and loop round, by its first active lane.
+#ifdef KAJO_COUNT_SPHERE_TESTS
 #define KAJO_COUNT_TESTS(lds, which)                                                                                   \
     do {                                                                                                               \
         if ((lds).testCounter) {                                                                                       \
@@ -1128,7 +1129,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     stage16(ldsPlaneRow, sc.planeRow, np);
     stage16(ldsSphereHot, sc.sphereHot, sc.nSphereHot);
     LdsScene lds;
-#ifdef KAJO_PROFILE
+#ifdef KAJO_COUNT_SPHERE_TESTS
     lds.testCounter = nullptr;
 #endif
     lds.planeRow = ldsPlaneRow;
@@ -1241,7 +1242,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     const int np = sc.nPlanes;
 
     // ---- stage the scene into LDS (one copy per workgroup) ------------------------------------
-#ifdef KAJO_PROFILE
+#ifdef KAJO_COUNT_SPHERE_TESTS
     LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
     lds.testCounter = args.counters ? args.counters + 29 : nullptr;
 #else

@@ -3,10 +3,10 @@ to back), work per path from the device counters, the algorithmic FLOP of SURVEY
   small scenes (every object walked):  FLOP/path = T (14 nPlanes + 28 nSpheres) + 150 V        T = closest-hit walks, V = vertices, per path
   grid scenes (configs[4]):            FLOP/path = W 14 nPlanes + 28 S + 150 V                 W = grid walks + list queries per path,
       S = sphere tests the RAYS' OWN walks run per path: the spheres registered in the cells a ray crosses up to its hit, the items of its
-      query's list up to its reach, the light itself -- counted per lane by the diagnostic twin (libkajo_hip_prof.so, KAJO_COUNT_TESTS) on a
+      query's list up to its reach, the light itself -- counted per lane by the diagnostic twin (libkajo_hip_count.so, KAJO_COUNT_TESTS) on a
       1920 x 1080 x 4-pass frame of the same scene and camera. The brute-force count of Raytracer.cpp:126-138 (1016 tests per walk) is not
       what a culled walk has to do; this is.
-usage: configs_roofline.py [out.json]   (needs kajo_amd/libkajo_hip_prof.so for the grid scene's S: make -C kajo_amd/csrc prof)"""
+usage: configs_roofline.py [out.json]   (needs kajo_amd/libkajo_hip_count.so for the grid scene's S: make -C kajo_amd/csrc count)"""
 import ctypes as C, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -47,7 +47,7 @@ cases = [  # key, label, scene, W, H, S, passes per frame (= per launch), depth
     ("configs[4]", "1000 spheres / 16 lights 3840x2160, 1024 spp = 32 x S32", stress, 3840, 2160, 32, 32, 8),
 ]
 tests = None
-prof = os.path.join(ROOT, "kajo_amd", "libkajo_hip_prof.so")
+prof = os.path.join(ROOT, "kajo_amd", "libkajo_hip_count.so")
 if os.path.exists(prof):
     p = subprocess.run([sys.executable, os.path.abspath(__file__), "--count-tests"], env=dict(os.environ, KAJO_HIP_LIB=prof), capture_output=True, text=True)
     if p.returncode == 0:
@@ -84,7 +84,7 @@ for key, label, sc, W, H, S, P, depth in cases:
             fpp = T * 14 * sc.n_planes + 28 * Sp + 150 * V
             row["model"] = "W 14 nPlanes + 28 S + 150 V, S = sphere tests of the rays' own culled walks (diagnostic twin)"
             row["sphere_tests_per_path"] = {"grid_walks": t["grid_sphere_tests"] / t["paths"], "list_walks": t["list_sphere_tests"] / t["paths"],
-                                            "lights": t["light_sphere_tests"] / t["paths"], "counted_on": "1920x1080 x 4 passes, libkajo_hip_prof.so"}
+                                            "lights": t["light_sphere_tests"] / t["paths"], "counted_on": "1920x1080 x 4 passes, libkajo_hip_count.so"}
             row["brute_force_model_flops_per_path"] = T * (14 * sc.n_planes + 28 * sc.n_spheres) + 150 * V
         else:
             fpp = None

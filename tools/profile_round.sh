@@ -10,6 +10,7 @@ R=${1:-r05}
 OUT=gpurun_out/${R}prof
 mkdir -p $OUT
 [ -f kajo_amd/libkajo_hip_prof.so ] || make -s -C kajo_amd/csrc prof || { echo "no profile twin" >&2; exit 1; }
+[ -f kajo_amd/libkajo_hip_count.so ] || make -s -C kajo_amd/csrc count || echo "no counting twin: the grid scene gets no roofline line" >&2
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_exact -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-seconds 0 > $OUT/stats_exact.log 2>&1

@@ -106,7 +106,7 @@ def test_exact_kernels_keep_their_register_budgets():
     instance carries the inline shadow walk and spills a few registers at that occupancy (measured: still the faster schedule)."""
     res, asm = _compile("exact")
     r = res["kajo_render_exact"]
-    assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["SGPRs Spill"] <= 6, r
+    assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["SGPRs Spill"] <= 10, r
     r = res["kajo_render_exact_split"]
     assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] <= 3, r
     r = res["kajo_render_exact_lights"]
@@ -125,16 +125,16 @@ def test_exact_kernels_keep_their_register_budgets():
 # Static VALU instruction counts of the small-scene kernels (the whole kernel, loops counted once), from the compiler's assembly of the
 # Makefile's own command. The loop's time follows its VALU instruction count (STRICT / FAST: 2.28 x the instructions, 2.26 x the time,
 # DESIGN.md section 4.3), and round 4 lost 2-3 % twice to changes that "only" added instructions to it (commit 8218d68). A change that
-# adds more than ~3 % has to raise its budget here, knowingly. Measured at the time of writing: 1396, 1360, 2130, 2331, 2679, 2880
-# (the STRICT / EXACT kernels carry two sphere loops since round 5 -- the one for scenes whose spheres are all (centre, radius)
-# records, +6.8 % / +5.2 %, and the general one: 76-132 instructions more in the text, fewer executed).
+# adds more than ~3 % has to raise its budget here, knowingly. Measured at the time of writing: 1396, 1360, 2227, 2471, 2766, 3003
+# (the STRICT / EXACT kernels carry two sphere loops and two plane loops since round 5 -- the ones for scenes of (centre, radius) spheres
+# and rigid planes, +7 % / +6.5 %, and the general ones: ~170-250 instructions more in the text, fewer executed).
 VALU_BUDGET = {
     ("fast", "kajo_render_fast"): 1440,
     ("fast", "kajo_render_fast_lights"): 1400,
-    ("exact", "kajo_render_exact"): 2190,
-    ("exact", "kajo_render_exact_lights"): 2400,
-    ("strict", "kajo_render_strict"): 2760,
-    ("strict", "kajo_render_strict_lights"): 2960,
+    ("exact", "kajo_render_exact"): 2290,
+    ("exact", "kajo_render_exact_lights"): 2540,
+    ("strict", "kajo_render_strict"): 2850,
+    ("strict", "kajo_render_strict_lights"): 3090,
 }
 
 

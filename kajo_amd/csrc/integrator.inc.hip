@@ -783,6 +783,83 @@ KDEV uint32_t shadowBin(const DSceneView& sc, const DSphereCold& lc, int lightK,
     return (uint32_t)(((lightK * 6 + face) * N) + ib);
 }
 
+// The cooperative walk of the visibility lists of one round of shadow queries (renderBody LISTS; described there). hasQ: this lane owns a
+// query (ray O, d; light sphere si at distance key keyL; list items [k0, e); reach reachQ). canHelp: this lane's ray registers are dead
+// -- it may take a share of another lane's list, and O, d are overwritten with that lane's. Returns, for an owner: some sphere of its
+// list lies in front of the light.
+KDEV bool listWalkCooperative(const DSceneView& sc, const LdsScene& lds, KajoLdsWord* helpOwner, KajoLdsWord* helpFlag, const uint32_t* items, int lane,
+                              bool hasQ, bool canHelp, F3& O, F3& d, uint32_t keyL, uint32_t k0, uint32_t e, int si, uint32_t reachQ)
+{
+    const unsigned long long qMask = __ballot(hasQ);
+    if (qMask == 0ull)
+        return false;
+    const unsigned long long idleMask = __ballot(!hasQ && canHelp);
+    const int nQ = __builtin_popcountll(qMask);
+    int G = __builtin_popcountll(idleMask) / nQ; // helpers per query
+    G = G > 7 ? 7 : G;
+    const unsigned long long mine = hasQ ? qMask : idleMask;
+    const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mine >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mine, 0u));
+    if (hasQ) {
+        helpOwner[rank] = (uint32_t)lane;
+        helpFlag[lane] = 0u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool helper = !hasQ && canHelp && rank < nQ * G;
+    int ownerLane = lane, sub = 0;
+    if (helper) {
+        const int qr = (int)(((float)rank + 0.5f) * __builtin_amdgcn_rcpf((float)G)); // rank / G (small integers)
+        sub = 1 + rank - qr * G;
+        ownerLane = (int)helpOwner[qr];
+    }
+    const int addr = ownerLane << 2;
+#define KAJO_FROM_OWNER_F(x) x = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr, __builtin_bit_cast(int, x)))
+#define KAJO_FROM_OWNER_U(x) x = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(x))
+    KAJO_FROM_OWNER_F(O.x);
+    KAJO_FROM_OWNER_F(O.y);
+    KAJO_FROM_OWNER_F(O.z);
+    KAJO_FROM_OWNER_F(d.x);
+    KAJO_FROM_OWNER_F(d.y);
+    KAJO_FROM_OWNER_F(d.z);
+    KAJO_FROM_OWNER_U(keyL);
+    KAJO_FROM_OWNER_U(k0);
+    KAJO_FROM_OWNER_U(e);
+    si = (int)__builtin_amdgcn_ds_bpermute(addr, si);
+    KAJO_FROM_OWNER_U(reachQ);
+#undef KAJO_FROM_OWNER_F
+#undef KAJO_FROM_OWNER_U
+    bool blocked = false;
+    if (hasQ || helper) {
+        const float aT = dot(d, d);
+#if KAJO_STRICT
+        const float iaT = 0.0f;
+#else
+        const float iaT = krcp(aT);
+#endif
+        const uint32_t stride = (uint32_t)G + 1u;
+        uint32_t j = k0 + (uint32_t)sub;
+        uint32_t nxt = 0xffffffffu;
+        if (j < e)
+            nxt = items[j];
+        while (j < e) {
+            const uint32_t cur = nxt;
+            j += stride;
+            if (j < e)
+                nxt = items[j];
+            if ((cur >> 16) > reachQ) // nothing further along the list can touch the ray before it ends
+                break;
+            KAJO_COUNT_TESTS(lds, 1);
+            if (shadowItemBlocks(sc, lds, (int)(cur & 0xffffu), si, O, d, aT, iaT, keyL)) {
+                blocked = true;
+                break;
+            }
+        }
+        if (helper && blocked)
+            helpFlag[ownerLane] = 1u;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return blocked || (hasQ && helpFlag[lane] != 0u);
+}
+
 // ---- surface point of an accepted hit ------------------------------------------------------
 struct Surface
 {
@@ -1045,10 +1122,9 @@ KDEV float lightPdf(const DSphereCold& lc, F3 P)
 }
 #endif
 
-KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
+// SphericalLight::generateSample (Light.cpp:39-49) from its three uniform variates
+KDEV F3 lightDirection(F3 centre, float radius, F3 P, float s1, float s2, float s3, float& pdf)
 {
-    rngStep(rng);
-    float s1 = unitBits((uint32_t)rng.lo), s2 = unitBits((uint32_t)(rng.lo >> 32)), s3 = unitBits((uint32_t)rng.hi);
 #if KAJO_STRICT
     float ang = (float)(2 * kPi * (double)s2);
     float sang, cang;
@@ -1067,6 +1143,13 @@ KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
     pdf = krcp(solidAngle(centre, radius, P));
 #endif
     return dir;
+}
+
+KDEV F3 lightGenerate(F3 centre, float radius, F3 P, Rng& rng, float& pdf)
+{
+    rngStep(rng);
+    const float s1 = unitBits((uint32_t)rng.lo), s2 = unitBits((uint32_t)(rng.lo >> 32)), s3 = unitBits((uint32_t)rng.hi);
+    return lightDirection(centre, radius, P, s1, s2, s3, pdf);
 }
 
 // ---- path state ---------------------------------------------------------------------------
@@ -1095,6 +1178,9 @@ enum : int
 #endif
 #ifndef KAJO_LISTS_TILE_RMW
 #define KAJO_LISTS_TILE_RMW 0
+#endif
+#ifndef KAJO_LISTS_BALANCED
+#define KAJO_LISTS_BALANCED 1 // 0: the light loop of rounds 4 (one vertex per lane), for A/B runs
 #endif
 #if KAJO_STRICT
 #define KAJO_IS_A_NUMBER(x) ((x) == (x))
@@ -1727,6 +1813,147 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             const uint32_t* items = sc.shadow.items;
             const int nL = sc.nLights;
             const bool canHelp = sampleNext || pathDone || mode == MODE_DONE; // (their O / d are rewritten before they are read again)
+#if KAJO_LISTS_BALANCED
+            // BALANCED (round 5): the unit of work of this loop is a (vertex, light) PAIR, not a vertex. Lights are taken two at a time, the
+            // same two for the whole wave: (A) every lane with a vertex draws the two lights' random numbers -- the one thing that is
+            // sequential per path (Light.cpp:39-41: one draw per light that is not the vertex itself) -- and decides which of them can
+            // count; (B) the wave's countable pairs (~50 of 128) are numbered and dealt to ALL lanes whose ray registers are dead, one
+            // pair each: the lane fetches the pair's vertex from its owner's registers (ds_bpermute), forms the sample, evaluates the BSDF
+            // toward it, runs the query's own part and takes part in the cooperative list walk as before; (C) the vertex's owner pulls
+            // contribution and answer back and adds them in light order. A vertex on the floor counts 15 of 16 lights, one under a sphere
+            // 3: with one vertex per lane the wave made as many rounds as its busiest lane has lights with 45 % of its lanes working;
+            // dealt as pairs the same work takes 8 rounds at ~80 %. Which lane forms a sample does not change it: same draws, same
+            // arithmetic, sums in light order -- STRICT stays the oracle bit for bit.
+            KajoLdsWord* pairTable = helpOwner; // [128] pair -> owner lane | (light of the chunk) << 6; rewritten every round (the list walk reuses the words)
+            const unsigned long long execMask = __ballot(canHelp);
+            const int H = __builtin_popcountll(execMask);
+            const int myRank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(execMask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)execMask, 0u));
+            for (int c0 = 0; c0 < nL; c0 += 2) {
+                // ---- (A) draws and countability of lights c0, c0 + 1 for every vertex of the wave
+                float sa0 = 0.0f, sa1 = 0.0f, sa2 = 0.0f, sb0 = 0.0f, sb1 = 0.0f, sb2 = 0.0f;
+                bool hasA = false, hasB = false;
+                for (int j = 0; j < 2; j++) {
+                    const int k = c0 + j;
+                    if (k >= nL)
+                        break;
+                    const int sk = lds.light[k];
+                    const DSphereCold& lk = lds.lightCold[k];
+                    if (sampleNext && np + 1 + sk != vId) { // a light does not sample itself (and draws nothing)
+                        const F3 toC = f3(lk.cx - vP.x, lk.cy - vP.y, lk.cz - vP.z);
+                        const bool below = dot(vN, toC) < -(1.001f * lk.radius + 1e-6f * (__builtin_fabsf(toC.x) + __builtin_fabsf(toC.y) + __builtin_fabsf(toC.z)));
+                        rngStep(rng);
+                        const float u1 = unitBits((uint32_t)rng.lo), u2 = unitBits((uint32_t)(rng.lo >> 32)), u3 = unitBits((uint32_t)rng.hi);
+                        // (a light that cannot count only draws: see the one-vertex-per-lane loop below for the two rules)
+                        bool countable = !(vKind == 2 || below);
+#if KAJO_STRICT
+                        countable = countable || (vKind == 0 && u1 > 0.999999f);
+#endif
+                        if (j == 0) {
+                            hasA = countable;
+                            sa0 = u1, sa1 = u2, sa2 = u3;
+                        } else {
+                            hasB = countable;
+                            sb0 = u1, sb1 = u2, sb2 = u3;
+                        }
+                    }
+                }
+                KAJO_STAMP(5);
+                const unsigned long long mA = __ballot(hasA), mB = __ballot(hasB);
+                const int nA = __builtin_popcountll(mA), P = nA + __builtin_popcountll(mB);
+                if (P == 0)
+                    continue;
+                const int pA = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mA >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mA, 0u));
+                const int pB = nA + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mB >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mB, 0u));
+                for (int base = 0; base < P; base += H) {
+                    // ---- (B) pairs base .. base + H - 1, one per lane that can work
+                    if (hasA)
+                        pairTable[pA] = (uint32_t)lane;
+                    if (hasB)
+                        pairTable[pB] = (uint32_t)lane | 64u;
+                    __builtin_amdgcn_wave_barrier();
+                    const int pMine = base + myRank;
+                    const bool worker = canHelp && pMine < P;
+                    uint32_t ow = (uint32_t)lane;
+                    if (worker)
+                        ow = pairTable[pMine];
+                    __builtin_amdgcn_wave_barrier();
+                    const bool second = (ow & 64u) != 0u;
+                    const int addrV = (int)(ow & 63u) << 2;
+#define KAJO_PULL_F(x) __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addrV, __builtin_bit_cast(int, x)))
+                    const F3 qP = f3(KAJO_PULL_F(vP.x), KAJO_PULL_F(vP.y), KAJO_PULL_F(vP.z));
+                    const F3 qN = f3(KAJO_PULL_F(vN.x), KAJO_PULL_F(vN.y), KAJO_PULL_F(vN.z));
+                    const F3 qR = f3(KAJO_PULL_F(vR.x), KAJO_PULL_F(vR.y), KAJO_PULL_F(vR.z));
+                    const F3 qColor = f3(KAJO_PULL_F(vColor.x), KAJO_PULL_F(vColor.y), KAJO_PULL_F(vColor.z));
+                    const float qExp = KAJO_PULL_F(vExp);
+                    const int qKind = __builtin_amdgcn_ds_bpermute(addrV, vKind);
+                    const float ta0 = KAJO_PULL_F(sa0), ta1 = KAJO_PULL_F(sa1), ta2 = KAJO_PULL_F(sa2);
+                    const float tb0 = KAJO_PULL_F(sb0), tb1 = KAJO_PULL_F(sb1), tb2 = KAJO_PULL_F(sb2);
+#undef KAJO_PULL_F
+                    const float s1 = second ? tb0 : ta0, s2 = second ? tb1 : ta1, s3 = second ? tb2 : ta2;
+                    bool hasQ = false;
+                    uint32_t keyL = 0, k0 = 0, e = 0, reachQ = 0;
+                    int si = 0;
+                    if (worker) {
+                        const int k = c0 + (second ? 1 : 0);
+                        si = lds.light[k];
+                        const DSphereCold& lc = lds.lightCold[k];
+                        float pl;
+                        d = lightDirection(f3(lc.cx, lc.cy, lc.cz), lc.radius, qP, s1, s2, s3, pl);
+#if !KAJO_RSTRICT
+                        pl = lightPdf(lc, qP);
+#endif
+                        float pb;
+                        const F3 fl = bsdfEvaluateWithPdf(qKind, qColor, qExp, qR, qN, d, pb);
+                        const float cosL = kmax0(dot(qN, d));
+                        O = qP + d * kEps;
+                        if (!(pl == 0.0f || pb == 0.0f || (cosL == 0.0f && KAJO_IS_A_NUMBER(pb)))) {
+                            const DFloat4 le = lds.lightEmission[k];
+                            pendContrib = ((rrcp(pb + pl) * fl) * cosL) * f3(le.x, le.y, le.z);
+                            ctrShadow += 1;
+                            KAJO_COUNT_TESTS(lds, 2);
+                            hasQ = lightReachedHead(sc, lds, k, si, O, d, keyL);
+                            if (hasQ) {
+                                uint32_t ia;
+                                const uint32_t row = shadowBin(sc, lc, k, le.w, O, ia, reachQ);
+                                const uint16_t* off = sc.shadow.off16 + row * (uint32_t)(sc.shadow.n + 1) + ia;
+                                const uint32_t rb = sc.shadow.rowBase[row];
+                                k0 = rb + off[0];
+                                e = rb + off[1];
+                            }
+                        }
+                    }
+                    KAJO_STAMP(6);
+                    const bool blocked = listWalkCooperative(sc, lds, helpOwner, helpFlag, items, lane, hasQ, canHelp, O, d, keyL, k0, e, si, reachQ);
+                    KAJO_STAMP(7);
+                    // ---- (C) answers back to the vertices' owners, in light order
+                    const bool reached = hasQ && !blocked;
+                    if (worker)
+                        helpOwner[pMine - base] = (uint32_t)lane; // (the list walk is done with the words)
+                    __builtin_amdgcn_wave_barrier();
+                    for (int j = 0; j < 2; j++) {
+                        const int pj = j == 0 ? pA : pB;
+                        const bool mine = (j == 0 ? hasA : hasB) && pj >= base && pj < base + H;
+                        int src = lane;
+                        if (mine)
+                            src = (int)helpOwner[pj - base];
+                        const int addrW = src << 2;
+                        const int got = __builtin_amdgcn_ds_bpermute(addrW, reached ? 1 : 0);
+                        const F3 cj = f3(__builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addrW, __builtin_bit_cast(int, pendContrib.x))),
+                                         __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addrW, __builtin_bit_cast(int, pendContrib.y))),
+                                         __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addrW, __builtin_bit_cast(int, pendContrib.z))));
+                        if (mine && got != 0) { // Shader.cpp:72-80: the closest hit is the light
+#if KAJO_RSTRICT
+                            vLd = vLd + cj;
+#else
+                            vE = vE + cj;
+#endif
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    KAJO_STAMP(8);
+                }
+            }
+#else
             int k = sampleNext ? lightK : nL;
             for (;;) {
                 bool hasQ = false;
@@ -1877,6 +2104,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 if (__ballot(k < nL) == 0ull)
                     break;
             }
+#endif
             if (sampleNext)
                 lightK = nL;
         }

@@ -39,8 +39,10 @@ for k, n in enumerate(names):
     print('%-18s executed in %5.1f%% of iterations, %4.1f lanes active when executed (%.0f%%)' % (n, 100 * ex / iters, la / max(ex, 1), 100 * la / max(ex, 1) / 64))
 st = [out[16 + k] for k in range(9)]
 if not DEFERRED and any(st[5:]):  # the large-scene kernels stamp inside their light loop: stamp 3 is then what follows the loop (BSDF sampling)
-    stamps = stamps[:3] + ['BSDF sampling (after the light loop)', stamps[4], 'light loop: samples + own part of the queries', 'light loop: helpers found, rays fetched',
-                           'light loop: lists walked', 'light loop: contributions added']
+    # (round 5, the balanced loop: the unit of work is a (vertex, light) pair dealt to any lane whose ray registers are dead)
+    stamps = stamps[:3] + ['BSDF sampling (after the light loop)', stamps[4], 'light loop (A): draws of two lights per vertex, which of them count',
+                           'light loop (B): pairs dealt, vertices fetched, samples + the queries\' own part', 'light loop: lists walked',
+                           'light loop (C): answers back to the vertices\' owners']
 tot = sum(st)
 for n, v in zip(stamps, st):
     print('%-46s %5.1f%% of wave time, %.0f cycles per iteration' % (n, 100 * v / tot, v / iters))

@@ -2366,7 +2366,10 @@ extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERN
     renderBody<true, false, false, false, true>(args, ldsRaw);
 }
 
-extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD) KAJO_KERNEL_NAME_LIGHTS(const RenderArgs args)
+#ifndef KAJO_WAVES_PER_SIMD_LIGHTS
+#define KAJO_WAVES_PER_SIMD_LIGHTS KAJO_WAVES_PER_SIMD
+#endif
+extern "C" __global__ void __launch_bounds__(256, KAJO_WAVES_PER_SIMD_LIGHTS) KAJO_KERNEL_NAME_LIGHTS(const RenderArgs args)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     renderBody<true, false>(args, ldsRaw);

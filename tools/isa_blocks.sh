@@ -4,7 +4,7 @@
 # Blocks are taken in LAYOUT order between consecutive marks; a loop inside a block is counted once (static counts).
 # usage: tools/isa_blocks.sh [fast|strict] [kernel name, default kajo_render_<mode>]
 HERE=$(cd "$(dirname "$0")/.." && pwd); C=$HERE/kajo_amd/csrc; K=${1:-fast}; KERNEL=${2:-kajo_render_$K}
-FP=$([ $K = fast ] && echo "-ffp-contract=fast -mllvm -amdgpu-sched-strategy=max-ilp" || echo -ffp-contract=off)
+FP=$([ $K = fast ] && echo "-ffp-contract=fast" || echo -ffp-contract=off)
 S=$(mktemp /tmp/isa_blocks.XXXXXX.s)
 hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I$HERE/include -I$C -fno-slp-vectorize $FP -DKAJO_MARKS -S --cuda-device-only -o $S $C/kernel_$K.hip 2>/dev/null || exit 1
 NAMES=("camera-ray block (after mark 4)" "traversal" "vertex / shadow-result" "light + BSDF" "tail" "light loop: samples + own part" "light loop: helpers, rays fetched" "light loop: lists walked" "light loop: contributions")

@@ -857,7 +857,7 @@ KDEV bool listWalkCooperative(const DSceneView& sc, const LdsScene& lds, KajoLds
             helpFlag[ownerLane] = 1u;
     }
     __builtin_amdgcn_wave_barrier();
-    return blocked || (hasQ && helpFlag[lane] != 0u);
+    return hasQ && (blocked || helpFlag[lane] != 0u); // (a helper's `blocked` is about somebody else's query)
 }
 
 // ---- surface point of an accepted hit ------------------------------------------------------

@@ -5,20 +5,25 @@ usage: pmc_summary.py <dir> [workload-name]"""
 import sys, os, csv, glob, collections, json
 out = sys.argv[1]
 workload = sys.argv[2] if len(sys.argv) > 2 else 'c2'
-agg = collections.defaultdict(lambda: collections.defaultdict(float))
-cnt = collections.defaultdict(lambda: collections.defaultdict(int))
-for f in glob.glob(os.path.join(out, '*', '*', '*counter_collection.csv')):
-    for row in csv.DictReader(open(f)):
-        k = row['Kernel_Name']
-        agg[k][row['Counter_Name']] += float(row['Counter_Value'])
-        cnt[k][row['Counter_Name']] += 1
+# Per counter: the MEDIAN over the kernel's dispatches of the pass (the bench's untimed launch with device counters on -- per-wave atomics --
+# once showed 198 MB of WRITE_SIZE where every timed launch has 32.4 MB: a mean would carry that into the traffic figure of the timed kernel),
+# from the NEWEST run of every pass directory (gpurun merges the files of several calls into one tree on the build side).
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sorted(glob.glob(os.path.join(out, '*', '*'))):
+    files = sorted(glob.glob(os.path.join(d, '*counter_collection.csv')), key=os.path.getmtime)
+    if not files:
+        continue
+    for row in csv.DictReader(open(files[-1])):
+        vals[row['Kernel_Name']][row['Counter_Name']].append(float(row['Counter_Value']))
+agg = {k: {c: sorted(v)[len(v) // 2] if len(v) % 2 else 0.5 * (sorted(v)[len(v) // 2 - 1] + sorted(v)[len(v) // 2]) for c, v in cs.items()} for k, cs in vals.items()}
+cnt = {k: {c: len(v) for c, v in cs.items()} for k, cs in vals.items()}
 res = {}
 for k in sorted(agg):
     if 'kajo_render' not in k: continue
     print('kernel', k)
-    per = {c: agg[k][c] / cnt[k][c] for c in agg[k]}
+    per = dict(agg[k])
     for c in sorted(per):
-        print('  %-32s per-launch %.6g  (launches %d)' % (c, per[c], cnt[k][c]))
+        print('  %-32s per-launch %.6g  (median of %d launches)' % (c, per[c], cnt[k][c]))
     d = {'workload': workload, 'counters_per_launch': per}
     if 'FETCH_SIZE' in per and 'WRITE_SIZE' in per:
         # KiB units; on gfx950 FETCH_SIZE counts 64 of every 128 bytes of a wide coalesced read (MI355X_MICROARCH.md, HBM)

@@ -31,7 +31,7 @@ a = {}
 for m in ("exact", "fast", "strict"):
     a.update(json.load(open("gpurun_out/pmc/${R}_%s/counters.json" % m)))
 for k, d in a.items():
-    d["collected"] = "round ${R}, MI355X, rocprofv3 --kernel-trace --pmc (six separate passes, tools/pmc.sh) over python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline" + (" --strict" if "strict" in k else " --fast" if "fast" in k else "")
+    d["collected"] = "round ${R}, MI355X, rocprofv3 --kernel-trace --pmc (six separate passes, tools/pmc.sh; per counter the median over the dispatches of a pass) over python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline" + (" --strict" if "strict" in k else " --fast" if "fast" in k else "")
 json.dump(a, open("$OUT/counters.json", "w"), indent=1, sort_keys=True)
 PY
 (echo "== EXACT"; python3 tools/configs.py exact; echo "== FAST"; python3 tools/configs.py; echo "== STRICT"; python3 tools/configs.py strict) > $OUT/configs.txt 2>&1

@@ -1,4 +1,5 @@
-// FAST numerics: the product path. Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast
+// FAST numerics: hardware transcendentals and FMA contraction everywhere -- the fastest of the three builds (bench.py fast_mode; the plugin runs
+// EXACT by default since round 5, kernel_exact.hip). Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=fast
 #define KAJO_STRICT 0
 #ifndef KAJO_WAVES_PER_SIMD
 #define KAJO_WAVES_PER_SIMD 5 // the FAST loop fits 96 VGPRs without spills (tools/vgpr_check.sh)

@@ -1,7 +1,8 @@
 """Seeded sweep over the parameters of kajo_hip_create / kajo_hip_render: frame sizes down to one pixel, every n =
 floor(sqrt(S)) from 1 up, depth limits 0..8, tile shapes, passes per launch (incl. launches that split the pass
-sequence), seeds, all golden scenes. The STRICT kernels must equal the oracle bit for bit on every draw; the FAST kernels
-must stay finite where the oracle is and close to it."""
+sequence), seeds, all golden scenes. The STRICT kernels must equal the oracle bit for bit on every draw; the EXACT kernels must
+have the oracle's not-a-number pixels and be within rounding of it everywhere else; the FAST kernels must stay finite where the
+oracle is and close to it."""
 import numpy as np
 import pytest
 
@@ -42,6 +43,16 @@ def test_strict_equals_oracle_on_random_parameters(scenes):
             got = r.render(c["passes"]).radiance()
         same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
         assert same[..., :3].all(), (c, int((~same[..., :3]).sum()))
+        # the EXACT build on the same draw: the same pixels not-a-number, every other within rounding (a path that decided
+        # differently moves its pixel by a path's share of it: per cents at these pass counts)
+        with HipRenderer(sc, c["W"], c["H"], spp=c["S"], depth_limit=c["depth"], seed=c["seed"], exact=True, tile=c["tile"],
+                         passes_per_launch=c["ppl"]) as r:
+            ex = r.render(c["passes"]).radiance()[..., :3]
+        fin = np.isfinite(want[..., :3]).all(-1)
+        assert np.array_equal(np.isfinite(ex).all(-1), fin), c
+        if fin.any():
+            rel = np.abs(ex - want[..., :3])[fin] / np.maximum(np.abs(want[..., :3][fin]), 1e-3)
+            assert rel.max() <= 1e-3, (c, float(rel.max()))
 
 
 def test_fast_close_to_oracle_on_random_parameters(scenes):
@@ -106,6 +117,16 @@ def test_strict_equals_oracle_on_random_large_scenes(scenes):
             got = TileLayout(W, H, owners).compose(np.stack(bufs))
             same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
             assert same[..., :3].all(), (draw, sc.name, W, H, S, passes, depth, ppl, owners, flags, int((~same[..., :3]).sum()))
+        # EXACT through the lists and through the grid: one buffer, the oracle's pixels not-a-number, the rest within rounding
+        ex = []
+        for flags in (0, capi.KAJO_FLAG_NO_SHADOW_LISTS):
+            with HipRenderer(sc, W, H, spp=S, depth_limit=depth, seed=seed, exact=True, passes_per_launch=ppl, flags=flags) as r:
+                ex.append(r.render(passes).radiance()[..., :3])
+        assert ((ex[0].view(np.uint32) == ex[1].view(np.uint32)) | (np.isnan(ex[0]) & np.isnan(ex[1]))).all(), (draw, sc.name)
+        fin = np.isfinite(want[..., :3]).all(-1)
+        assert np.array_equal(np.isfinite(ex[0]).all(-1), fin), (draw, sc.name)
+        rel = np.abs(ex[0] - want[..., :3])[fin] / np.maximum(np.abs(want[..., :3][fin]), 1e-3)
+        assert rel.max() <= 2e-3, (draw, sc.name, float(rel.max()))
         fast = []
         for flags in (0, capi.KAJO_FLAG_NO_SHADOW_LISTS):
             with HipRenderer(sc, W, H, spp=S, depth_limit=depth, seed=seed, passes_per_launch=ppl, flags=flags) as r:

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""STRICT kernels against the oracle over WHOLE frames of the BASELINE configs (not crops): how many pixels differ in a bit, where, and
-the NaN pixels on both sides. The oracle runs on the host cores (minutes for the big ones).
+"""STRICT and EXACT kernels against the oracle over WHOLE frames of the BASELINE configs (not crops): how many pixels differ in a bit (STRICT),
+clamped RMSE / pixels off by more than 1e-3 (EXACT), and the NaN pixels on both sides. The oracle runs on the host cores (minutes for the big ones).
 usage: whole_frame.py [seed=<stream seed>] [c2] [c3] [c4] [c5] [test] ... [mix:<scene seed>] [stress:<spheres>:<lights>:<scene seed>]
 mix:<n> = a seeded small scene of this tool's own: the room of spheres.json with its planes' materials drawn anew (diffuse, Phong, ideal
 reflector), 8-20 spheres under ROTATED transforms (the general-sphere records) -- diffuse, Phong, mirror, glass of several indices --
@@ -69,7 +69,17 @@ for key in (keys or ["c2", "c4", "test"]):
         got = r.render(P).radiance()
     a, b = got[..., :3], want[..., :3]
     differ = ((a.view(np.uint32) != b.view(np.uint32)) & ~(np.isnan(a) & np.isnan(b))).any(-1)
-    print("%-52s %9d px: %d differ; NaN px kernel %d oracle %d; oracle %.0f s on %d threads" % (
+    print("%-52s %9d px: STRICT %d differ; NaN px kernel %d oracle %d; oracle %.0f s on %d threads" % (
         name, W * H, int(differ.sum()), int(np.isnan(a).any(-1).sum()), int(np.isnan(b).any(-1).sum()), t_or, threads), flush=True)
+    # the EXACT build (round 5) on the same frame: which pixels are not-a-number, how far the rest is from the oracle
+    with HipRenderer(sc, W, H, spp=S, depth_limit=depth, seed=SEED, exact=True, passes_per_launch=ppl) as r:
+        ex = r.render(P).radiance()[..., :3]
+    ne, nw = ~np.isfinite(ex).all(-1), ~np.isfinite(b).all(-1)
+    ok = ~(ne | nw)
+    ge, gw = ex[ok].astype(np.float64) / P, b[ok].astype(np.float64) / P
+    cl = np.clip(ge, 0, 1) - np.clip(gw, 0, 1)
+    print("%-52s            EXACT: NaN px %d (oracle %d, both %d); clamped RMSE %.3e; px off by > 1e-3: %d; max relative %.2e" % (
+        "", int(ne.sum()), int(nw.sum()), int((ne & nw).sum()), float(np.sqrt(np.mean(cl ** 2))), int((np.abs(cl).max(-1) > 1e-3).sum()),
+        float((np.abs(ge - gw) / np.maximum(np.abs(gw), 1e-3)).max())), flush=True)
     for y, x in np.argwhere(differ)[:8]:
         print("     (%d, %d) kernel %s oracle %s" % (x, y, a[y, x], b[y, x]), flush=True)

@@ -1,6 +1,7 @@
 """One-off soak of the large-scene kernels (pair loop, visibility lists, grid): seeded draws of scenes with 48-500 spheres and 1-40 lights, ragged frames,
 pass splits, depth limits. STRICT must equal the oracle's every-object walk bit for bit; EXACT must have its not-a-number pixels and stay within rounding;
-FAST with lists must equal FAST through the grid. usage: large_scene_soak.py [draws=30] [seed=1]"""
+FAST with lists must equal FAST through the grid. `kind=small`: the small-scene kernels instead, on the generated rooms of rotated spheres of every
+material with 1-4 lights (tests/scenes_extra.py). usage: large_scene_soak.py [draws=30] [seed=1] [kind=large|small]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]
@@ -12,7 +13,8 @@ from kajo_amd.scene import Scene, stress_scene
 from oraclelib import OracleLib
 from test_shadow_lists_cpu import adversarial_scene
 kw = dict(a.split("=") for a in sys.argv[1:])
-draws, seed0 = int(kw.get("draws", 30)), int(kw.get("seed", 1))
+draws, seed0, kind = int(kw.get("draws", 30)), int(kw.get("seed", 1)), kw.get("kind", "large")
+from scenes_extra import mixed_scene
 z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
 base = Scene.from_npz(z, "spheres_a169/", "s")
 lib = OracleLib("oracle")
@@ -20,7 +22,9 @@ rng = np.random.default_rng(seed0)
 bad = 0
 for draw in range(draws):
     nl = int(rng.choice([1, 2, 3, 5, 7, 8, 15, 16, 17, 24, 33, 40]))
-    if draw % 4 == 3:
+    if kind == "small":
+        sc = mixed_scene(base, int(rng.integers(1, 1000000)))
+    elif draw % 4 == 3:
         sc = adversarial_scene(base, int(rng.integers(10, 100000)), n=int(rng.integers(60, 200)), n_lights=min(nl, 12))
     else:
         sc = stress_scene(base, int(rng.integers(48, 500)), nl, seed=int(rng.integers(1, 100000)))

@@ -204,7 +204,11 @@ def mode_leg(scene, W, H, passes, ppl, local_rank, numerics, fpp):
 
     r = HipRenderer(scene, W, H, spp=SPP, depth_limit=DEPTH, seed=SEED, strict=(numerics == "strict"), exact=(numerics == "exact"),
                     device=local_rank, passes_per_launch=ppl)
-    got = r.render(passes).radiance()  # (first launch: also records the launch order)
+    # the first launch measures the blocks; from the second on the launches run in cost order with the cheapest blocks in parts
+    # (FAST / EXACT; capi.cpp partTheTail) -- the parity leg gets the frame AS THE TIMED LAUNCHES RENDER IT
+    r.render(passes).wait()
+    r.reset()
+    got = r.render(passes).radiance()
     r.render(passes).wait()
     c0 = r.counters()
     t0 = time.perf_counter()
@@ -219,7 +223,7 @@ def mode_leg(scene, W, H, passes, ppl, local_rank, numerics, fpp):
     kernel_ms = (c1["kernelMs"] - c0["kernelMs"]) / launches
     achieved = fpp * (c1["paths"] - c0["paths"]) / launches / (kernel_ms * 1e-3) / 1e12
     return {"numerics": numerics, "value": (c1["paths"] - c0["paths"]) / reps / dt / 1e6, "unit": "Msamples/s",
-            "ms_per_step": dt * 1e3, "kernel_ms_per_launch": kernel_ms,
+            "ms_per_step": dt * 1e3, "kernel_ms_per_launch": kernel_ms, "tail_groups_per_launch": int(c1.get("tailGroups", 0)),
             "roofline": {"bound": "valu", "achieved": achieved, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_TFLOPS,
                          "kernel": "kajo_render_" + numerics, "flops_per_path": fpp}}, got
 

@@ -64,7 +64,8 @@ extern "C" {
 #define KAJO_FLAG_DEFERRED 64u  /* EXPERIMENT, round 3 (measured slower; only in kajo_amd/libkajo_hip_exp.so of `make
                                    experiments`, refused by the product library): surviving vertices are parked in LDS and the light / BSDF
                                    sampling blocks run only in trips where enough lanes have one (deferred.inc.hip) */
-#define KAJO_FLAG_NO_SPLIT 16u  /* small frames: do not let several waves share a pixel block and divide the passes */
+#define KAJO_FLAG_NO_SPLIT 16u  /* small frames: do not let several waves share a pixel block and divide the passes; large frames
+                                   (FAST / EXACT): do not render the cheapest blocks of a launch in parts (KajoCounters.tailGroups) */
 #define KAJO_FLAG_NO_SHADOW_LISTS 128u /* large scenes: shadow rays walk the uniform grid as extension rays do, instead of being answered
                                    from the lights' visibility lists inside the light loop (same results; for A/B runs and tests) */
 #define KAJO_FLAG_EXACT 512u  /* decision-exact numerics (round 5): the oracle's arithmetic (KAJO_FLAG_STRICT's) wherever a value can reach a
@@ -102,6 +103,8 @@ typedef struct KajoCounters {
     uint64_t launches;       /* render kernel launches */
     uint64_t shadowQueries;  /* large scenes: shadow rays answered from the lights' visibility lists inside the light loop (they
                                 are not among `traversals`, which then counts camera and extension rays only) */
+    uint64_t tailGroups;     /* of the last render launch: workgroups beyond one per pixel block -- the cheapest blocks of a large frame
+                                are rendered in 2 or 4 parts so that the launch ends on short jobs (FAST / EXACT; 0 = not parted) */
 } KajoCounters;
 
 typedef struct KajoHip* kajo_hip_t;

@@ -72,6 +72,7 @@ class KajoCounters(C.Structure):
         ("kernelMs", C.c_double),
         ("launches", C.c_uint64),
         ("shadowQueries", C.c_uint64),  # (appended in round 4; the experiment libraries of earlier rounds leave it 0)
+        ("tailGroups", C.c_uint64),  # (appended in round 5)
     ]
 
 

@@ -24,3 +24,29 @@ extern "C" int kajo_compose_launch(const void* gathered, const TileMap* map, voi
                        static_cast<const float4*>(gathered), *map, static_cast<float4*>(frame));
     return (int)hipGetLastError();
 }
+
+// Launch tail (integrator.inc.hip PARTS, capi.cpp partedOrder): blocks rendered in 2 or 4 parts have part 0's sum -- the pixel's total so
+// far plus its passes -- in `tiles` and the later parts' sums in the side buffers; the total is their sum in part order. One workgroup per
+// such block, `threads` = the render kernel's workgroup size (a block's slots are block * threads ...). Plain additions, no products: the
+// result does not depend on the contraction setting of this file.
+extern "C" __global__ void __launch_bounds__(256) kajo_fold_parts(float4* tiles, const float4* side, uint32_t sideStride, const uint32_t* blocks)
+{
+    const uint32_t word = blocks[blockIdx.x];
+    const uint32_t slot = (word & 0x0fffffffu) * blockDim.x + threadIdx.x;
+    const int parts = 1 << (word >> 30);
+    float4 t = tiles[slot];
+    for (int k = 1; k < parts; k++) {
+        const float4 s = side[(size_t)(k - 1) * sideStride + slot];
+        t.x += s.x;
+        t.y += s.y;
+        t.z += s.z;
+    }
+    tiles[slot] = t;
+}
+
+extern "C" int kajo_fold_parts_launch(void* tiles, const void* side, uint32_t sideStride, const uint32_t* blocks, unsigned count, unsigned threads, void* stream)
+{
+    hipLaunchKernelGGL(kajo_fold_parts, dim3(count), dim3(threads), 0, static_cast<hipStream_t>(stream), static_cast<float4*>(tiles),
+                       static_cast<const float4*>(side), sideStride, blocks);
+    return (int)hipGetLastError();
+}

@@ -39,6 +39,7 @@ int kajo_resolve_strict_launch(const void* frame, int count, float passes, void*
 int kajo_resolve_tiles_fast_launch(const void* gathered, const TileMap* map, float passes, void* dst, void* stream);
 int kajo_resolve_tiles_strict_launch(const void* gathered, const TileMap* map, float passes, void* dst, void* stream);
 int kajo_compose_launch(const void* gathered, const TileMap* map, void* frame, void* stream);
+int kajo_fold_parts_launch(void* tiles, const void* side, uint32_t sideStride, const uint32_t* blocks, unsigned count, unsigned threads, void* stream);
 int kajo_kat_shade_fast_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_kat_shade_strict_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_kat_trace_fast_launch(const KatTraceArgs*, unsigned grid, size_t lds, void* stream);
@@ -113,6 +114,14 @@ struct KajoHip
     uint32_t* blockOrder = nullptr;  // device [grid]
     bool orderValid = false, tripsPending = false;
     unsigned gridBlocks = 0;
+    // launch tail (updateBlockOrder): the same order with its cheapest blocks in 2 or 4 parts, the blocks that have parts, their side buffers
+    uint32_t* partedOrder = nullptr; // device [partedGrid]
+    uint32_t* partedBlocks = nullptr; // device [nParted]
+    unsigned partedGrid = 0, nParted = 0;
+    int partsMax = 1;            // 1, 2 or 4: a launch uses the parted order when its passes divide by this
+    bool sideTiles = false;      // three side buffers follow `tiles` in its allocation (float4 [3][slotsPerOwner], zeroed with it)
+    int waveSlots = 0;           // waves the chip holds at once with this handle's kernel (updateBlockOrder)
+    unsigned lastTailGroups = 0; // KajoCounters.tailGroups
     unsigned wavesPerBlock = 1; // workgroup = 64 * wavesPerBlock threads: single-wave groups dispatch and retire
                                 // independently (measured +2.3 % over 4-wave groups)
     int passesDone = 0;
@@ -247,6 +256,10 @@ void destroy(KajoHip* h)
         (void)hipFree(h->waveTrips);
     if (h->blockOrder)
         (void)hipFree(h->blockOrder);
+    if (h->partedOrder)
+        (void)hipFree(h->partedOrder);
+    if (h->partedBlocks)
+        (void)hipFree(h->partedBlocks);
     if (h->ownStream && h->stream)
         (void)hipStreamDestroy(h->stream);
     delete h;
@@ -564,8 +577,11 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         h->nTilesOwned = 0;
     m.slotsPerOwner = h->tilesPerOwner * p.tileW * p.tileH;
     h->tileBytes = (size_t)m.slotsPerOwner * 16;
-    CREATE_TRY(hipMalloc(&h->tiles, h->tileBytes));
-    CREATE_TRY(hipMemsetAsync(h->tiles, 0, h->tileBytes, h->stream));
+    // (FAST / EXACT handles that order their launches: room for the three side buffers of the launch tail behind the tile buffer,
+    // partTheTail; slots outside the image are never written and stay zero)
+    h->sideTiles = h->numerics() != 1 && !(p.flags & (KAJO_FLAG_NO_SPLIT | KAJO_FLAG_NO_REORDER)) && m.slotsPerOwner < (1 << 28);
+    CREATE_TRY(hipMalloc(&h->tiles, h->tileBytes * (h->sideTiles ? 4 : 1)));
+    CREATE_TRY(hipMemsetAsync(h->tiles, 0, h->tileBytes * (h->sideTiles ? 4 : 1), h->stream));
     if (p.flags & KAJO_FLAG_COUNTERS) {
         CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->counters), 32 * sizeof(unsigned long long)));
         CREATE_TRY(hipMemsetAsync(h->counters, 0, 32 * sizeof(unsigned long long), h->stream));
@@ -711,6 +727,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
                 chunks = 1;
         }
         hipError_t le;
+        h->lastTailGroups = 0;
         if (chunks > 1) {
             RenderArgs b = a;
             b.blockOrder = nullptr;
@@ -732,7 +749,20 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         } else {
             // (coldInLds 2: the small-scene instance of any number of lights although the scene has one, KAJO_FLAG_NO_ONE_LIGHT)
             const int home = (h->coldInLds && (h->params.flags & KAJO_FLAG_NO_ONE_LIGHT)) ? 2 : h->coldInLds;
-            le = (hipError_t)h->launchRender(&a, home, grid, block, ldsTotal);
+            // the launch tail: the cheapest blocks in parts when the passes divide (updateBlockOrder)
+            const bool parted = h->orderValid && h->nParted && now % h->partsMax == 0 && now / h->partsMax >= 2;
+            if (parted) {
+                h->lastTailGroups = h->partedGrid - grid;
+                RenderArgs b = a;
+                b.blockOrder = h->partedOrder;
+                b.sideStride = (uint32_t)h->map.slotsPerOwner;
+                le = (hipError_t)h->launchRender(&b, home, h->partedGrid, block, ldsTotal);
+                if (le == hipSuccess)
+                    le = (hipError_t)kajo_fold_parts_launch(h->tiles, static_cast<char*>(h->tiles) + h->tileBytes, b.sideStride, h->partedBlocks, h->nParted, block,
+                                                            h->stream);
+            } else {
+                le = (hipError_t)h->launchRender(&a, home, grid, block, ldsTotal);
+            }
         }
         if (le != hipSuccess) {
             h->eventPool.push_back(e0);
@@ -756,6 +786,57 @@ int kajo_hip_render(kajo_hip_t h, int passes)
 namespace
 {
 
+// The launch tail. Workgroups are dispatched in order as wave slots come free, so a launch ends while its last `waveSlots` jobs run out:
+// on average half such a job per slot stands idle -- 3 % of a 1920x1080 launch (six rounds of the slots), 1 % at 3840x2160. The cheapest
+// blocks, last in the order, are therefore rendered as 2 or 4 workgroups of half / a quarter of the passes each (integrator.inc.hip PARTS):
+// the launch ends on short jobs. Short waves are the less efficient ones (lanes run out of passes to take over: 16 -> 4 passes per wave
+// costs 10 %, tools/ppl_sweep.py), so only the tail is parted. FAST and EXACT only: a sum of partial sums is not the oracle's sum.
+int partTheTail(KajoHip* h, const std::vector<uint32_t>& order)
+{
+    h->nParted = 0;
+    const unsigned n = (unsigned)order.size();
+    if (!h->sideTiles || n >= (1u << 28))
+        return KAJO_OK;
+    if (!h->waveSlots) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        h->waveSlots = cus * 4 * (h->coldInLds ? 5 : 4); // (launch bounds of the small-scene / large-scene kernels)
+    }
+    const unsigned slots = (unsigned)h->waveSlots / h->wavesPerBlock;
+    // in eighths of the slots: blocks in four parts (the very last), blocks in two parts (before them)
+    int q4 = 2, q2 = 2; // (measured: tools/tail_sweep.sh -- 2/2 ... 4/4 within 0.2 % of each other, 8/8 half the gain)
+    KAJO_TUNE_INT("KAJO_TAIL_Q4", 0, 64, q4);
+    KAJO_TUNE_INT("KAJO_TAIL_Q2", 0, 64, q2);
+    if (n < 2 * slots) // (frames of one or two rounds: the SPLIT kernels' business)
+        return KAJO_OK;
+    const unsigned n4 = std::min<unsigned>(n / 2, (unsigned)((unsigned long long)slots * q4 / 8));
+    const unsigned n2 = std::min<unsigned>(n / 2 - n4, (unsigned)((unsigned long long)slots * q2 / 8));
+    if (n4 + n2 == 0)
+        return KAJO_OK;
+    std::vector<uint32_t> parted, blocks;
+    parted.reserve(n + n2 + 3 * (size_t)n4);
+    for (unsigned i = 0; i < n; i++) {
+        const uint32_t partLog = i >= n - n4 ? 2u : (i >= n - n4 - n2 ? 1u : 0u);
+        for (uint32_t k = 0; k < (1u << partLog); k++)
+            parted.push_back(order[i] | (k << 28) | (partLog << 30));
+        if (partLog)
+            blocks.push_back(order[i] | (partLog << 30));
+    }
+    if (h->partedOrder)
+        (void)hipFree(h->partedOrder);
+    if (h->partedBlocks)
+        (void)hipFree(h->partedBlocks);
+    h->partedOrder = h->partedBlocks = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->partedOrder), parted.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->partedBlocks), blocks.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(h->partedOrder, parted.data(), parted.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->partedBlocks, blocks.data(), blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->partedGrid = (unsigned)parted.size();
+    h->nParted = (unsigned)blocks.size();
+    h->partsMax = n4 ? 4 : 2;
+    return KAJO_OK;
+}
+
 // Longest-processing-time-first order of the workgroups from the trips the first launch recorded
 // (a block runs as long as its slowest wave).
 int updateBlockOrder(KajoHip* h)
@@ -775,7 +856,7 @@ int updateBlockOrder(KajoHip* h)
     std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
     HIP_TRY(hipMemcpy(h->blockOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
     h->orderValid = true;
-    return KAJO_OK;
+    return partTheTail(h, order);
 }
 
 } // namespace
@@ -1093,6 +1174,7 @@ int kajo_hip_counters(kajo_hip_t h, KajoCounters* out)
     out->paths = pixels * (unsigned long long)(n * n) * (unsigned long long)h->passesDone;
     out->kernelMs = h->kernelMs;
     out->launches = h->launches;
+    out->tailGroups = h->lastTailGroups;
     if (h->counters) {
         unsigned long long c[4];
         HIP_TRY(hipMemcpy(c, h->counters, sizeof c, hipMemcpyDeviceToHost));

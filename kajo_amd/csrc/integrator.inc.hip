@@ -1334,27 +1334,45 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #else
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
 #endif
+    // Launch tail (capi.cpp partedOrder): the cheapest blocks of a launch -- the ones dispatched last -- may come as 2 or 4 workgroups of
+    // nPasses / 2 (/ 4) passes each, so that the launch ends on short jobs. Part 0 continues the pixel's total in the tile buffer; part
+    // k > 0 sums its passes from zero into side buffer k - 1, and a fold kernel adds the side buffers in part order after the launch.
+    // Not in the STRICT build: the oracle adds the passes' terms one by one (Renderer.cpp:70-71), a sum of partial sums is not that sum.
+    constexpr bool PARTS = !KAT && !SPLIT && !KAJO_RSTRICT && !(LISTS && KAJO_LISTS_TILE_RMW);
+    const uint32_t orderWord = (!KAT && args.blockOrder) ? args.blockOrder[blockIdx.x] : blockIdx.x;
+    const uint32_t logicalBlock = PARTS ? (orderWord & 0x0fffffffu) : orderWord;
+    const int partLog = PARTS ? (int)(orderWord >> 30) : 0, part = PARTS ? (int)((orderWord >> 28) & 3u) : 0;
+    const int stealWindow = args.stealWindow;
+    const int partPasses = args.nPasses >> partLog, partFirst = args.firstPass + part * partPasses;
     if (threadIdx.x == 0) { // what only the camera-ray block needs of the launch: kept out of the scalar registers
         DFloat4* cam = const_cast<DFloat4*>(lds.camera);
         cam[5] = DFloat4{args.pixelWidth, args.pixelHeight, args.sampleWidth, args.sampleHeight};
         cam[6] = DFloat4{__builtin_bit_cast(float, (uint32_t)args.seed ^ 0x79622d32u), __builtin_bit_cast(float, (uint32_t)(args.seed >> 32) ^ 0x6b206574u),
                          __builtin_bit_cast(float, args.W), __builtin_bit_cast(float, args.H)};
+        // (PARTS: the bounds of the workgroup's passes depend on the order word, a loaded value -- two more scalars alive through the loop,
+        // in kernels that have none to spare. They are needed where a pass is taken over and after the loop only: the camera block's free words.)
+        if (PARTS) {
+            const int last = partFirst + partPasses;
+            cam[0].w = __builtin_bit_cast(float, last);
+            cam[1].w = __builtin_bit_cast(float, last - stealWindow > partFirst ? last - stealWindow : partFirst);
+        }
     }
     __syncthreads();
 
     // per-wave mailbox for taken-over passes: [lane][stealWindow] float4, behind the scene copy (render_args.h)
-    const int stealWindow = args.stealWindow;
     DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.perWaveOffset + (threadIdx.x >> 6) * args.perWaveBytes);
 
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;
-    const uint32_t logicalBlock = (!KAT && args.blockOrder) ? args.blockOrder[blockIdx.x] : blockIdx.x;
     const int splitWave = SPLIT ? (int)(threadIdx.x >> 6) : 0;
     const int splitCount = SPLIT ? (int)(blockDim.x >> 6) : 1;
-    const uint32_t slot = SPLIT ? logicalBlock * 64u + (uint32_t)lane : logicalBlock * blockDim.x + threadIdx.x; // index into the tile buffer
+    const uint32_t pixelSlot = SPLIT ? logicalBlock * 64u + (uint32_t)lane : logicalBlock * blockDim.x + threadIdx.x; // index into the tile buffer
+    // (part k > 0: the same slot of side buffer k - 1 -- the side buffers follow the tile buffer, sideStride slots each; nothing more to
+    // carry through the loop than the slot itself)
+    const uint32_t slot = PARTS ? pixelSlot + (uint32_t)part * args.sideStride : pixelSlot;
     // SPLIT: per-pass terms of the block, [nPasses][64] float4 behind the scene copy
     DFloat4* termTable = reinterpret_cast<DFloat4*>(ldsRaw + args.mailboxOffset);
-    const int wave = (int)(slot >> 6);
+    const int wave = (int)(pixelSlot >> 6);
     const int wavesPerTile = (args.tileW >> 3) * (args.tileH >> 3);
     const int ownedTile = wave / wavesPerTile;
     const int wb = wave - ownedTile * wavesPerTile;
@@ -1378,7 +1396,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // (LISTS_RMW: the large-scene list kernels of rounds 3-4 -- 128 VGPRs and spilling -- did not carry the pixel's total through the loop:
     // a pass end added its term to the tile buffer in place, 32 bytes of traffic per pixel and PASS instead of per launch)
     constexpr bool LISTS_RMW = LISTS && KAJO_LISTS_TILE_RMW;
-    if (!KAT && !LISTS_RMW && inImage) {
+    if (!KAT && !LISTS_RMW && inImage && part == 0) {
         const float4 t = reinterpret_cast<const float4*>(args.tiles)[slot];
         total = f3(t.x, t.y, t.z);
         totalW = t.w;
@@ -1395,13 +1413,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // order (Renderer.cpp:66) and adds the terms in pass order.
     const int chunks = SPLIT ? args.sampleChunks : 0;
     const bool bySample = SPLIT && chunks > 1;
-    const int passesMine = bySample ? 1 : (SPLIT ? args.nPasses / splitCount : args.nPasses); // the host launches SPLIT only when this divides
-    const int firstMine = args.firstPass + (bySample ? splitWave / chunks : splitWave * passesMine);
+    const int passesMine = bySample ? 1 : (SPLIT ? args.nPasses / splitCount : partPasses); // the host launches SPLIT / parts only when this divides
+    const int firstMine = SPLIT ? args.firstPass + (bySample ? splitWave / chunks : splitWave * passesMine) : partFirst;
     const int sampleBegin = bySample ? (splitWave % chunks) * (n * n / chunks) : 0;
     const int sampleEnd = bySample ? sampleBegin + n * n / chunks : n * n; // (sampleY, sampleX) == (endY, endX): the lane's samples of the pass are done
     const int endY = sampleEnd / n, endX = sampleEnd % n;
     int pass = firstMine;                       // pass being rendered (own or taken over)
-    const int lastPass = firstMine + passesMine; // exclusive
+    const int lastPassS = firstMine + passesMine; // exclusive
     // Pass stealing. A pass of a pixel is a self-contained piece of work (its n*n paths have their own
     // streams, its sum enters the pixel's total as one term), so a lane that has finished its own pixel
     // takes over the LAST not-yet-started pass of a lane that still has several to go, renders it, and
@@ -1409,9 +1427,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // pass order -- the float sums are formed exactly as without stealing. Only the last `stealWindow`
     // passes of a launch can be given away (that is all the imbalance there is, and bounds the mailbox).
     int ownPass = firstMine; // next pass of the lane's own pixel
-    int myEnd = inImage ? lastPass : firstMine; // own passes [ownPass, myEnd); shrinks when one is taken over
+    int myEnd = inImage ? lastPassS : firstMine; // own passes [ownPass, myEnd); shrinks when one is taken over
     int stolenFrom = -1;          // lane whose pass is being rendered, or -1
-    const int stealBase = lastPass - stealWindow > firstMine ? lastPass - stealWindow : firstMine;
+    const int stealBaseS = lastPassS - stealWindow > firstMine ? lastPassS - stealWindow : firstMine;
+#define lastPass (PARTS ? __builtin_bit_cast(int, lds.camera[0].w) : lastPassS)
+#define stealBase (PARTS ? __builtin_bit_cast(int, lds.camera[1].w) : stealBaseS)
     int sampleX = sampleBegin % n, sampleY = sampleBegin / n;
     F3 radiance = f3(0.0f, 0.0f, 0.0f); // sum over the pixel's samples of this pass
     Rng rng{0, 0};
@@ -2326,6 +2346,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
         reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
     }
+#undef lastPass
+#undef stealBase
     if (!KAT && !SPLIT && args.waveTrips && lane == 0)
         args.waveTrips[slot >> 6] = trips;
 

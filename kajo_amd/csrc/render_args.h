@@ -33,6 +33,10 @@ struct RenderArgs
     // workgroups. Pure scheduling: the buffer slot of a pixel does not depend on it.
     const uint32_t* blockOrder;   // [grid] logical block run by physical block i; null = identity
     uint32_t* waveTrips;          // [grid * 4] loop trips of every wave of the launch; null = not recorded
+    // Launch tail: bits 30-31 of an order word = log2 of the parts its block is rendered in (0: one workgroup renders all nPasses
+    // passes), bits 28-29 = which part this workgroup is, bits 0-27 the block. Part k > 0 writes its sum to slot + k * sideStride: three
+    // side buffers follow the tile buffer in the same allocation.
+    uint32_t sideStride;          // slots per buffer; 0 unless the order holds parts
     // known-answer mode (kajo_hip_kat_shade): lane i runs ONE path from a given ray and RNG state
     const float* katRays;         // [katCount][6] origin, direction
     const uint64_t* katStates;    // [katCount][2]

@@ -65,14 +65,16 @@ extern "C" {
                                    experiments`, refused by the product library): surviving vertices are parked in LDS and the light / BSDF
                                    sampling blocks run only in trips where enough lanes have one (deferred.inc.hip) */
 #define KAJO_FLAG_NO_SPLIT 16u  /* small frames: do not let several waves share a pixel block and divide the passes; large frames
-                                   (FAST / EXACT): do not render the cheapest blocks of a launch in parts (KajoCounters.tailGroups) */
+                                   (FAST / EXACT): do not render the cheapest blocks of a launch in parts (KajoCounters.tailGroups).
+                                   Scheduling only: the frame is the same bit for bit with and without */
 #define KAJO_FLAG_NO_SHADOW_LISTS 128u /* large scenes: shadow rays walk the uniform grid as extension rays do, instead of being answered
                                    from the lights' visibility lists inside the light loop (same results; for A/B runs and tests) */
 #define KAJO_FLAG_EXACT 512u  /* decision-exact numerics (round 5): the oracle's arithmetic (KAJO_FLAG_STRICT's) wherever a value can reach a
                                    decision -- the closest-hit walk, hit points, normals, sampled directions, coins -- so every path meets the
                                    oracle's objects, draws its random numbers and ends in its generator state; the fast forms where a value
                                    only scales radiance (BSDF values and pdfs, the light pdf, MIS weights, throughput products). The buffer
-                                   differs from KAJO_FLAG_STRICT's in the last places of each path's radiance. Not with KAJO_FLAG_STRICT. */
+                                   differs from KAJO_FLAG_STRICT's in the last places of each path's radiance (and of the sums over the
+                                   passes: see kajo_hip_render). Not with KAJO_FLAG_STRICT. */
 #define KAJO_FLAG_NO_ONE_LIGHT 256u /* small scenes with exactly one light, every numerics build: run the kernel instance of any number of lights
                                    (kajo_render_*_lights) instead of the one that samples the BSDF in the light's visit (same results in the
                                    FAST and EXACT builds bit for bit and in the STRICT build, which stays the oracle; the hold thresholds
@@ -104,7 +106,9 @@ typedef struct KajoCounters {
     uint64_t shadowQueries;  /* large scenes: shadow rays answered from the lights' visibility lists inside the light loop (they
                                 are not among `traversals`, which then counts camera and extension rays only) */
     uint64_t tailGroups;     /* of the last render launch: workgroups beyond one per pixel block -- the cheapest blocks of a large frame
-                                are rendered in 2 or 4 parts so that the launch ends on short jobs (FAST / EXACT; 0 = not parted) */
+                                of a small scene are rendered as four workgroups of a quarter of the passes each, so that the launch
+                                ends on short jobs (FAST / EXACT, launches of 8, 16, 32 ... passes; the frame is the same bit for bit;
+                                0 = not parted) */
 } KajoCounters;
 
 typedef struct KajoHip* kajo_hip_t;
@@ -115,7 +119,13 @@ void kajo_hip_default_params(KajoParams* p);
 int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoParams* params, kajo_hip_t* out);
 int kajo_hip_destroy(kajo_hip_t h); /* NULL is accepted */
 
-/* Enqueue `passes` more passes (pass numbers continue from the handle's count, first = 1; at most 2^31 - 1 in all). */
+/* Enqueue `passes` more passes (pass numbers continue from the handle's count, first = 1; at most 2^31 - 1 in all).
+   How the passes' terms radiance / S enter a pixel's total (Renderer.cpp:70-71): STRICT adds them one by one, as the reference does.
+   FAST and EXACT (small scenes) add the passes of one launch -- at most passesPerLaunch passes of a call -- group by group: a launch
+   of 8, 16, 32 ... passes that starts on a multiple of a quarter of its size is four groups, any other launch one; a group is summed
+   from zero in pass order and then added to the total. The same terms in another order of additions (last place of the total), chosen
+   so that the work of a launch can be divided -- among waves, workgroups (KajoCounters.tailGroups) or GPUs -- without changing a bit:
+   the frame depends on the sequence of render() calls, not on how the handle or a scheduler divided them. */
 int kajo_hip_render(kajo_hip_t h, int passes);
 int kajo_hip_wait(kajo_hip_t h);
 /* Zero the accumulation and restart the pass numbering at 1. */

@@ -118,7 +118,6 @@ struct KajoHip
     uint32_t* partedOrder = nullptr; // device [partedGrid]
     uint32_t* partedBlocks = nullptr; // device [nParted]
     unsigned partedGrid = 0, nParted = 0;
-    int partsMax = 1;            // 1, 2 or 4: a launch uses the parted order when its passes divide by this
     bool sideTiles = false;      // three side buffers follow `tiles` in its allocation (float4 [3][slotsPerOwner], zeroed with it)
     int waveSlots = 0;           // waves the chip holds at once with this handle's kernel (updateBlockOrder)
     unsigned lastTailGroups = 0; // KajoCounters.tailGroups
@@ -130,7 +129,11 @@ struct KajoHip
     int thrL = 1, holdTrips = 1; // integrator.inc.hip MODE_HOLD
     int ldsExtra = 0;    // (KAJO_TUNING builds only) unused bytes per wave, to study a launch at a lower occupancy
     int helpBytes = 0;   // list scenes: [64] owner lanes + [64] blocker flags of the cooperative list walk (integrator.inc.hip), behind the mailbox
-    size_t perWaveBytes(bool withMailbox) const { return (size_t)ldsExtra + (size_t)helpBytes + (withMailbox ? (size_t)64 * stealWindow * 16 : 0); }
+    int accBytes = 0;    // FAST / EXACT, small scenes: [64] float4, the lanes' running totals behind the mailbox (integrator.inc.hip GROUPS)
+    size_t perWaveBytes(bool withMailbox) const
+    {
+        return (size_t)ldsExtra + (size_t)helpBytes + (withMailbox ? (size_t)64 * stealWindow * 16 + (size_t)accBytes : 0);
+    }
     void fillWaveLds(RenderArgs& a, size_t perWaveOffset, bool withMailbox) const
     {
         a.perWaveOffset = (uint32_t)perWaveOffset;
@@ -547,6 +550,13 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     }
     h->hotBytes = hotBytes + gridHeaderBytes + gridBytes; // what the big-scene staging (and the known-answer kernels) put in LDS
     h->coldInLds = !big;
+    if (h->coldInLds && h->numerics() != 1) {
+        // (the lanes' running totals take the room of one pass of the mailbox: three passes to take over instead of four costs nothing,
+        // tools/steal_window_sweep.sh, and the scene copy + a wave's area of BASELINE's scenes stays within a fifth wave per SIMD's share)
+        h->accBytes = 64 * 16;
+        h->stealWindow = 3;
+        KAJO_TUNE_INT("KAJO_STEAL_WINDOW", 1, 16, h->stealWindow);
+    }
     h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0) + gridHeaderBytes + gridBytes;
     // every workgroup stages its own LDS copy of the scene: single-wave groups only while that copy is small
     h->wavesPerBlock = h->ldsBytes <= 6 * 1024 ? 1 : 4;
@@ -577,9 +587,9 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         h->nTilesOwned = 0;
     m.slotsPerOwner = h->tilesPerOwner * p.tileW * p.tileH;
     h->tileBytes = (size_t)m.slotsPerOwner * 16;
-    // (FAST / EXACT handles that order their launches: room for the three side buffers of the launch tail behind the tile buffer,
-    // partTheTail; slots outside the image are never written and stay zero)
-    h->sideTiles = h->numerics() != 1 && !(p.flags & (KAJO_FLAG_NO_SPLIT | KAJO_FLAG_NO_REORDER)) && m.slotsPerOwner < (1 << 28);
+    // (FAST / EXACT handles of small scenes that order their launches: room for the three side buffers of the launch tail behind the
+    // tile buffer, partTheTail; slots outside the image are never written and stay zero)
+    h->sideTiles = h->coldInLds && h->numerics() != 1 && !(p.flags & (KAJO_FLAG_NO_SPLIT | KAJO_FLAG_NO_REORDER)) && m.slotsPerOwner < (1 << 28);
     CREATE_TRY(hipMalloc(&h->tiles, h->tileBytes * (h->sideTiles ? 4 : 1)));
     CREATE_TRY(hipMemsetAsync(h->tiles, 0, h->tileBytes * (h->sideTiles ? 4 : 1), h->stream));
     if (p.flags & KAJO_FLAG_COUNTERS) {
@@ -681,6 +691,10 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         const int now = left < perLaunch ? left : perLaunch;
         a.firstPass = h->passesDone + 1;
         a.nPasses = now;
+        // (integrator.inc.hip GROUPS: the total takes the passes of this launch in four groups when they are 8, 16, 32 ...)
+        // and the passes before it are whole groups of that size (pass numbers decide where a group ends: the same on every GPU of a frame)
+        const bool quartered = now >= 8 && (now & (now - 1)) == 0 && h->passesDone % (now / 4) == 0;
+        a.groupPasses = quartered ? now / 4 : (1 << 30);
         hipEvent_t e0, e1;
         if ((rc = getEvent(h, &e0)) || (rc = getEvent(h, &e1)))
             return rc;
@@ -750,7 +764,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
             // (coldInLds 2: the small-scene instance of any number of lights although the scene has one, KAJO_FLAG_NO_ONE_LIGHT)
             const int home = (h->coldInLds && (h->params.flags & KAJO_FLAG_NO_ONE_LIGHT)) ? 2 : h->coldInLds;
             // the launch tail: the cheapest blocks in parts when the passes divide (updateBlockOrder)
-            const bool parted = h->orderValid && h->nParted && now % h->partsMax == 0 && now / h->partsMax >= 2;
+            const bool parted = h->orderValid && h->nParted && quartered;
             if (parted) {
                 h->lastTailGroups = h->partedGrid - grid;
                 RenderArgs b = a;
@@ -788,9 +802,10 @@ namespace
 
 // The launch tail. Workgroups are dispatched in order as wave slots come free, so a launch ends while its last `waveSlots` jobs run out:
 // on average half such a job per slot stands idle -- 3 % of a 1920x1080 launch (six rounds of the slots), 1 % at 3840x2160. The cheapest
-// blocks, last in the order, are therefore rendered as 2 or 4 workgroups of half / a quarter of the passes each (integrator.inc.hip PARTS):
-// the launch ends on short jobs. Short waves are the less efficient ones (lanes run out of passes to take over: 16 -> 4 passes per wave
-// costs 10 %, tools/ppl_sweep.py), so only the tail is parted. FAST and EXACT only: a sum of partial sums is not the oracle's sum.
+// blocks, last in the order, are therefore rendered as FOUR workgroups of a quarter of the passes each (integrator.inc.hip PARTS): the
+// launch ends on short jobs. Short waves are the less efficient ones (a lane that has run out of passes can only take over whole ones:
+// 16 -> 4 passes per wave costs 10 %, tools/ppl_sweep.py), so only the tail is parted. FAST and EXACT kernels of small scenes, whose
+// totals take the passes of a launch in four groups whoever renders them (integrator.inc.hip GROUPS): the frame does not change by a bit.
 int partTheTail(KajoHip* h, const std::vector<uint32_t>& order)
 {
     h->nParted = 0;
@@ -803,14 +818,13 @@ int partTheTail(KajoHip* h, const std::vector<uint32_t>& order)
         h->waveSlots = cus * 4 * (h->coldInLds ? 5 : 4); // (launch bounds of the small-scene / large-scene kernels)
     }
     const unsigned slots = (unsigned)h->waveSlots / h->wavesPerBlock;
-    // in eighths of the slots: blocks in four parts (the very last), blocks in two parts (before them)
-    int q4 = 2, q2 = 2; // (measured: tools/tail_sweep.sh -- 2/2 ... 4/4 within 0.2 % of each other, 8/8 half the gain)
+    // how many blocks, in eighths of the slots (measured: tools/tail_sweep.sh)
+    int q4 = 4;
     KAJO_TUNE_INT("KAJO_TAIL_Q4", 0, 64, q4);
-    KAJO_TUNE_INT("KAJO_TAIL_Q2", 0, 64, q2);
     if (n < 2 * slots) // (frames of one or two rounds: the SPLIT kernels' business)
         return KAJO_OK;
     const unsigned n4 = std::min<unsigned>(n / 2, (unsigned)((unsigned long long)slots * q4 / 8));
-    const unsigned n2 = std::min<unsigned>(n / 2 - n4, (unsigned)((unsigned long long)slots * q2 / 8));
+    const unsigned n2 = 0; // (halves would be another sum: the groups are quarters)
     if (n4 + n2 == 0)
         return KAJO_OK;
     std::vector<uint32_t> parted, blocks;
@@ -833,7 +847,6 @@ int partTheTail(KajoHip* h, const std::vector<uint32_t>& order)
     HIP_TRY(hipMemcpy(h->partedBlocks, blocks.data(), blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     h->partedGrid = (unsigned)parted.size();
     h->nParted = (unsigned)blocks.size();
-    h->partsMax = n4 ? 4 : 2;
     return KAJO_OK;
 }
 

@@ -1334,11 +1334,17 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #else
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
 #endif
-    // Launch tail (capi.cpp partedOrder): the cheapest blocks of a launch -- the ones dispatched last -- may come as 2 or 4 workgroups of
-    // nPasses / 2 (/ 4) passes each, so that the launch ends on short jobs. Part 0 continues the pixel's total in the tile buffer; part
-    // k > 0 sums its passes from zero into side buffer k - 1, and a fold kernel adds the side buffers in part order after the launch.
-    // Not in the STRICT build: the oracle adds the passes' terms one by one (Renderer.cpp:70-71), a sum of partial sums is not that sum.
-    constexpr bool PARTS = !KAT && !SPLIT && !KAJO_RSTRICT && !(LISTS && KAJO_LISTS_TILE_RMW);
+    // GROUPS (FAST / EXACT, small scenes): the pixel's total takes the passes of a launch in groups -- a quarter of the launch's passes each
+    // when they are 8, 16, 32 ... (args.groupPasses; else one group): every group is summed from zero in pass order, the group sums are
+    // added to the total in group order. A sum any division of the launch's work can form: one wave rendering all passes of a pixel block
+    // (the group sum in `total`, the running total in an LDS word of the lane), several waves dividing the passes (SPLIT: wave 0 adds
+    // the terms of the table group by group), or -- PARTS, the launch tail (capi.cpp partTheTail) -- the cheapest blocks of a launch, the
+    // ones dispatched last, as FOUR workgroups of a quarter of the passes each, so that the launch ends on short jobs: part 0 adds its
+    // group to the total in the tile buffer, part k > 0 leaves its group's sum in side buffer k - 1, and a fold kernel adds the side
+    // buffers in part order after the launch. The frame does not depend on which blocks were parted, nor on how many GPUs shared it.
+    // Not in the STRICT build: the oracle adds the passes' terms one by one (Renderer.cpp:70-71), and a sum of group sums is not that sum.
+    constexpr bool GROUPS = !KAT && !KAJO_RSTRICT && COLD_LDS;
+    constexpr bool PARTS = GROUPS && !SPLIT;
     const uint32_t orderWord = (!KAT && args.blockOrder) ? args.blockOrder[blockIdx.x] : blockIdx.x;
     const uint32_t logicalBlock = PARTS ? (orderWord & 0x0fffffffu) : orderWord;
     const int partLog = PARTS ? (int)(orderWord >> 30) : 0, part = PARTS ? (int)((orderWord >> 28) & 3u) : 0;
@@ -1355,6 +1361,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             const int last = partFirst + partPasses;
             cam[0].w = __builtin_bit_cast(float, last);
             cam[1].w = __builtin_bit_cast(float, last - stealWindow > partFirst ? last - stealWindow : partFirst);
+            // a group ends before pass p when ((p - 1) & groupMask) == 0: groupPasses is a power of two, and the launch's first pass -- they
+            // are numbered from 1 -- begins a group (render_args.h)
+            cam[2].w = __builtin_bit_cast(float, args.groupPasses - 1);
         }
     }
     __syncthreads();
@@ -1396,7 +1405,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     // (LISTS_RMW: the large-scene list kernels of rounds 3-4 -- 128 VGPRs and spilling -- did not carry the pixel's total through the loop:
     // a pass end added its term to the tile buffer in place, 32 bytes of traffic per pixel and PASS instead of per launch)
     constexpr bool LISTS_RMW = LISTS && KAJO_LISTS_TILE_RMW;
-    if (!KAT && !LISTS_RMW && inImage && part == 0) {
+    // (PARTS kernels: `total` is the sum of the group of passes the lane is in; the running total waits in the lane's LDS word behind the mailbox)
+    DFloat4* const accWord = mailbox + 64 * stealWindow + lane;
+    if (PARTS) {
+        if (inImage) {
+            const float4 t = part == 0 ? reinterpret_cast<const float4*>(args.tiles)[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            *accWord = DFloat4{t.x, t.y, t.z, t.w};
+        }
+    } else if (!KAT && !LISTS_RMW && inImage) {
         const float4 t = reinterpret_cast<const float4*>(args.tiles)[slot];
         total = f3(t.x, t.y, t.z);
         totalW = t.w;
@@ -1559,6 +1575,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         total = total + term;
                     }
                     ownPass++;
+                    if (PARTS) { // a group of passes complete
+                        // (also when it was the last group: what is added after the loop is a zero then)
+                        if (((ownPass - 1) & __builtin_bit_cast(int, lds.camera[2].w)) == 0) {
+                            const DFloat4 a = *accWord;
+                            *accWord = DFloat4{a.x + total.x, a.y + total.y, a.z + total.z, a.w};
+                            total = f3(0.0f, 0.0f, 0.0f);
+                        }
+                    }
                 }
                 radiance = f3(0.0f, 0.0f, 0.0f);
                 sampleX = sampleBegin % n;
@@ -2314,7 +2338,15 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     if (SPLIT) {
         __syncthreads(); // every wave of the block has left its loop: the table is complete
         if (splitWave == 0 && inImage) {
+            // (GROUPS: `group` is the sum of the group of passes p is in, `total` the total the complete groups have been added to)
+            F3 group = f3(0.0f, 0.0f, 0.0f);
+            const int gMask = args.groupPasses - 1;
             for (int p = 0; p < args.nPasses; p++) { // Renderer.cpp:70-71, pass by pass
+                if (GROUPS && p > 0 && (p & gMask) == 0) {
+                    total = total + group;
+                    group = f3(0.0f, 0.0f, 0.0f);
+                }
+                F3 term;
                 if (bySample) {
                     F3 sum = f3(0.0f, 0.0f, 0.0f);
                     for (int k = 0; k < n * n; k++) { // Renderer.cpp:66, sample by sample
@@ -2322,15 +2354,21 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         sum = sum + f3(t.x, t.y, t.z);
                     }
 #if KAJO_RSTRICT
-                    total = total + f3(kdiv(sum.x, args.S), kdiv(sum.y, args.S), kdiv(sum.z, args.S));
+                    term = f3(kdiv(sum.x, args.S), kdiv(sum.y, args.S), kdiv(sum.z, args.S));
 #else
-                    total = total + sum * invS;
+                    term = sum * invS;
 #endif
-                    continue;
+                } else {
+                    const DFloat4 t = termTable[p * 64 + lane];
+                    term = f3(t.x, t.y, t.z);
                 }
-                const DFloat4 t = termTable[p * 64 + lane];
-                total = total + f3(t.x, t.y, t.z);
+                if (GROUPS)
+                    group = group + term;
+                else
+                    total = total + term;
             }
+            if (GROUPS)
+                total = total + group;
             reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
         }
     } else if (!KAT && inImage) {
@@ -2340,9 +2378,24 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             totalW = t4.w;
         }
         // passes of this pixel that other lanes rendered, in pass order
-        for (int p = myEnd; p < lastPass; p++) {
-            const DFloat4 t = mailbox[lane * stealWindow + (p - stealBase)];
-            total = total + f3(t.x, t.y, t.z);
+        if (PARTS) {
+            const int gMask = __builtin_bit_cast(int, lds.camera[2].w);
+            DFloat4 a = *accWord;
+            for (int p = myEnd; p < lastPass; p++) {
+                if (p > myEnd && ((p - 1) & gMask) == 0) { // (a group that ended with the lane's own last pass is in the word already)
+                    a = DFloat4{a.x + total.x, a.y + total.y, a.z + total.z, a.w};
+                    total = f3(0.0f, 0.0f, 0.0f);
+                }
+                const DFloat4 t = mailbox[lane * stealWindow + (p - stealBase)];
+                total = total + f3(t.x, t.y, t.z);
+            }
+            total = f3(a.x + total.x, a.y + total.y, a.z + total.z); // the last group (a zero if the lane rendered its last pass itself)
+            totalW = a.w;
+        } else {
+            for (int p = myEnd; p < lastPass; p++) {
+                const DFloat4 t = mailbox[lane * stealWindow + (p - stealBase)];
+                total = total + f3(t.x, t.y, t.z);
+            }
         }
         reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
     }

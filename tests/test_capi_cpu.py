@@ -30,7 +30,7 @@ def test_pod_layout_matches_header():
     from kajo_amd import scene as S
     assert C.sizeof(S.KajoMaterial) == 88 and C.sizeof(S.KajoSphere) == 156 and C.sizeof(S.KajoPlane) == 152
     assert C.sizeof(S.KajoCamera) == 128
-    assert C.sizeof(capi.KajoParams) == 48 and C.sizeof(capi.KajoCounters) == 72
+    assert C.sizeof(capi.KajoParams) == 48 and C.sizeof(capi.KajoCounters) == 80
 
 
 @pytest.mark.skipif(not available("oracle"), reason="oracle not built")

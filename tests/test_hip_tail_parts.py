@@ -1,11 +1,12 @@
-"""The launch tail (kajo_amd/csrc/capi.cpp partTheTail, integrator.inc.hip PARTS, aux_kernels.hip kajo_fold_parts).
+"""The launch tail (kajo_amd/csrc/capi.cpp partTheTail, integrator.inc.hip GROUPS / PARTS, aux_kernels.hip kajo_fold_parts).
 
-From the second launch on -- the first measures the blocks -- the FAST and EXACT builds render the cheapest blocks of a large frame
-as 2 or 4 workgroups of half / a quarter of the launch's passes each, so that the launch ends on short jobs (+2.3 % at 1920x1080,
-profiles/r05_notes.txt). What that may change: a parted block's pixel total is  (total so far + passes of part 0) + passes of part 1
-+ ...  instead of the passes' terms added one by one (Renderer.cpp:70-71) -- the same terms, each rendered from the same streams, in
-another order of float additions: last places. What it must not change: anything else; pixels of blocks that are not parted keep
-their bits; the result does not depend on which workgroup finishes first; STRICT -- the oracle's sum, term by term -- is never parted."""
+From the second launch on -- the first measures the blocks -- the FAST and EXACT builds render the cheapest blocks of a large frame of
+a small scene as FOUR workgroups of a quarter of the launch's passes each, so that the launch ends on short jobs (+2 % at 1920x1080,
+profiles/r05_notes.txt). That must not change a bit of the frame: in these builds the pixel's total takes the passes of a launch of
+8, 16, 32 ... passes in four groups -- each summed from zero in pass order, the group sums added in group order -- whoever renders them:
+one wave all of them, several waves of a small frame dividing the passes (the SPLIT kernels), or the four workgroups of a parted block.
+So the frame does not depend on which blocks were parted, on the launch order, or on how many GPUs shared the frame. STRICT adds the
+passes' terms one by one, as the oracle does (Renderer.cpp:70-71), and is never parted."""
 import numpy as np
 import pytest
 
@@ -18,77 +19,82 @@ SEED = 0o715517
 W, H = 1280, 720  # 14 400 pixel blocks: more than two rounds of the chip's 5 120 wave slots, the least the tail is parted for
 
 
-def two_launches(sc, passes=8, **kw):
-    with HipRenderer(sc, W, H, seed=SEED, passes_per_launch=passes, **kw) as r:
-        r.render(passes).wait()
-        first = r.counters()["tailGroups"]
-        r.render(passes).wait()
-        return r.radiance()[..., :3].copy(), first, r.counters()["tailGroups"]
+def launches(sc, passes=(8, 8), w=W, h=H, **kw):
+    """-> radiance after the launches, tailGroups after each"""
+    groups = []
+    with HipRenderer(sc, w, h, seed=SEED, passes_per_launch=max(passes), **kw) as r:
+        for p in passes:
+            r.render(p).wait()
+            groups.append(r.counters()["tailGroups"])
+        return r.radiance()[..., :3].copy(), groups
 
 
 @pytest.mark.parametrize("mode", ["fast", "exact"])
-def test_parted_tail_is_the_unparted_sum_to_the_last_places(scenes, mode):
+def test_parted_tail_does_not_change_a_bit(scenes, mode):
     sc = scenes["spheres_a169"]
     kw = dict(exact=True) if mode == "exact" else {}
-    a, first, second = two_launches(sc, **kw)
-    assert first == 0 and second > 0, (first, second)  # the first launch has no measured order yet
-    b, f0, s0 = two_launches(sc, flags=capi.KAJO_FLAG_NO_SPLIT, **kw)
-    assert f0 == 0 and s0 == 0
-    nan_a, nan_b = ~np.isfinite(a).all(-1), ~np.isfinite(b).all(-1)
-    assert np.array_equal(nan_a, nan_b)
-    ok = ~nan_a
-    same = (a == b).all(-1) | nan_a
-    # 2 560 of the 14 400 blocks are parted (a quarter of the wave slots in four parts, a quarter in two): everything else keeps its bits
-    assert same.mean() >= 0.80, same.mean()
-    assert same.mean() < 1.0  # (if nothing differs the parts did not run)
-    rel = np.abs(a - b)[ok] / np.maximum(np.abs(b[ok]), 1e-3)
-    assert rel.max() <= 2e-6, rel.max()  # sums of 16 terms in another order: a few units in the last place
-    # whole 8x8 blocks differ or do not
-    blocks = same[: H // 8 * 8, : W // 8 * 8].reshape(H // 8, 8, W // 8, 8)
-    parted = ~blocks.all(axis=(1, 3))
-    assert 0 < parted.sum() <= 2560, parted.sum()
-    # ... and the same bits whichever workgroup of a block finishes first: a second handle
-    c, _, _ = two_launches(sc, **kw)
+    a, g = launches(sc, (16, 16, 8), **kw)
+    assert g[0] == 0 and g[1] > 0 and g[2] > 0, g  # the first launch has no measured order yet
+    assert g[1] % 3 == 0 and 1000 <= g[1] // 3 <= 14400 // 2  # three more workgroups for every parted block
+    b, g0 = launches(sc, (16, 16, 8), flags=capi.KAJO_FLAG_NO_SPLIT, **kw)
+    assert g0 == [0, 0, 0]
+    assert np.array_equal(a, b, equal_nan=True)
+    # ... nor does the order of the launch: workgroups in image order
+    c, _ = launches(sc, (16, 16, 8), flags=capi.KAJO_FLAG_NO_REORDER, **kw)
     assert np.array_equal(a, c, equal_nan=True)
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_small_frames_divided_among_waves_form_the_same_sums(scenes, mode):
+    """A 256 x 144 crop-sized frame runs the SPLIT kernels (several waves share a pixel block and divide the passes; wave 0 adds the
+    terms): the same groups. Compared with the same frame rendered without the division."""
+    sc = scenes["spheres_a169"]
+    kw = dict(exact=True) if mode == "exact" else {}
+    for passes in ((16,), (8, 16), (4, 6, 8)):
+        a, _ = launches(sc, passes, w=256, h=144, **kw)
+        b, _ = launches(sc, passes, w=256, h=144, flags=capi.KAJO_FLAG_NO_SPLIT, **kw)
+        assert np.array_equal(a, b, equal_nan=True), passes
+
+
+def test_groups_are_sums_of_the_same_terms(scenes):
+    """What the groups may change against adding pass by pass: the order of float additions. The EXACT frame of 16 passes in one launch
+    (four groups) against the same 16 passes in launches of 2 (each launch one group: pass by pass up to a zero added first)."""
+    sc = scenes["spheres_a169"]
+    a, _ = launches(sc, (16,), w=320, h=180, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT)
+    b, _ = launches(sc, (2,) * 8, w=320, h=180, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT)
+    ok = np.isfinite(b).all(-1)
+    assert np.array_equal(ok, np.isfinite(a).all(-1))
+    rel = np.abs(a - b)[ok] / np.maximum(np.abs(b[ok]), 1e-3)
+    assert 0 < rel.max() <= 2e-6, rel.max()
 
 
 def test_strict_is_never_parted(scenes):
     sc = scenes["spheres_a169"]
-    a, first, second = two_launches(sc, strict=True)
-    assert first == 0 and second == 0
-    b, _, _ = two_launches(sc, strict=True, flags=capi.KAJO_FLAG_NO_SPLIT)
+    a, g = launches(sc, (16, 16), strict=True)
+    assert g == [0, 0]
+    b, _ = launches(sc, (16, 16), strict=True, flags=capi.KAJO_FLAG_NO_SPLIT)
+    assert np.array_equal(a, b, equal_nan=True)
+    # pass by pass: the launches' boundaries do not matter to STRICT
+    c, _ = launches(sc, (8, 6, 2, 16), strict=True)
+    assert np.array_equal(a, c, equal_nan=True)
+
+
+def test_only_launches_of_8_16_32_passes_on_a_group_boundary_are_parted(scenes):
+    """Groups are quarters of a launch of 8, 16, 32 ... passes that starts where a group of its size would (pass numbers decide where a
+    group ends, so that every GPU of a frame forms the same sums); any other launch is one group, rendered whole."""
+    sc = scenes["spheres_a169"]
+    seq = (8, 6, 2, 16, 12, 4, 16, 6, 16)  # passes done before each: 0, 8, 14, 16, 32, 44, 48, 64, 70
+    a, g = launches(sc, seq, exact=True)
+    assert [x > 0 for x in g] == [False, False, False, True, False, False, True, False, False], g
+    b, _ = launches(sc, seq, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT)
     assert np.array_equal(a, b, equal_nan=True)
 
 
-def test_launches_whose_passes_do_not_divide_are_not_parted(scenes):
-    """Parts are halves and quarters of the launch's passes, two passes at least: 6 passes are rendered whole."""
-    sc = scenes["spheres_a169"]
-    with HipRenderer(sc, W, H, seed=SEED, passes_per_launch=16, exact=True) as r:
-        r.render(8).wait()
-        r.render(6).wait()
-        assert r.counters()["tailGroups"] == 0
-        r.render(4).wait()  # quarters of one pass: no
-        assert r.counters()["tailGroups"] == 0
-        r.render(16).wait()
-        assert r.counters()["tailGroups"] > 0
-        got = r.radiance()[..., :3]
-    with HipRenderer(sc, W, H, seed=SEED, passes_per_launch=16, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT) as r:
-        for p in (8, 6, 4, 16):
-            r.render(p).wait()
-        want = r.radiance()[..., :3]
-    ok = np.isfinite(want).all(-1)
-    assert np.array_equal(ok, np.isfinite(got).all(-1))
-    assert (np.abs(got - want)[ok] / np.maximum(np.abs(want[ok]), 1e-3)).max() <= 2e-6
-
-
-def test_large_scene_kernels_part_their_tail_too(scenes):
-    """The 300-sphere scene (uniform grid, no lists) and the 1000-sphere one (grid + visibility lists) at 1280x720: four waves per
-    SIMD there, 4 096 slots."""
+def test_large_scenes_are_not_parted(scenes):
+    """The large-scene kernels (uniform grid; cold records in global memory) add pass by pass in every build."""
     from kajo_amd.scene import stress_scene
-    for sc in (stress_scene(scenes["spheres_a169"], 300, 6, seed=7), stress_scene(scenes["spheres_a169"], 1000, 16)):
-        a, first, second = two_launches(sc, exact=True)
-        assert first == 0 and second > 0
-        b, _, _ = two_launches(sc, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT)
-        ok = np.isfinite(b).all(-1)
-        assert np.array_equal(ok, np.isfinite(a).all(-1))
-        assert (np.abs(a - b)[ok] / np.maximum(np.abs(b[ok]), 1e-3)).max() <= 2e-6
+    sc = stress_scene(scenes["spheres_a169"], 300, 6, seed=7)
+    a, g = launches(sc, (8, 8), exact=True)
+    assert g == [0, 0]
+    b, _ = launches(sc, (4, 4, 8), exact=True)
+    assert np.array_equal(a, b, equal_nan=True)

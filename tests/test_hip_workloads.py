@@ -94,7 +94,7 @@ def check_against_reference_fixture(golden, key, scene, crops, passes, strict, f
             g = fast[y:y + h, x:x + w, :3]
             rm = clamped_rmse(g / passes, ref_s / passes)
             m = np.isfinite(g) & np.isfinite(ref_s)
-            row.update(fast_vs_reference_O2_rmse=rm, fast_median_abs=float(np.median(np.abs(g - ref_s)[m] / passes)))
+            row.update(fast_vs_reference_O2_rmse=rm, fast_median_abs=float(np.median((np.abs(g - ref_s) / np.maximum(passes, np.abs(ref_s)))[m])))
             assert rm <= max(1e-3, fast_slack * floor), (key, k, rm, floor)
             # (the 1000-sphere scene: small spheres far from the origin, whose hit points binary32 resolves to ~1e-4 whatever the
             # formula -- the reference's own two builds differ by more than FAST differs from either)
@@ -146,7 +146,9 @@ def check_workload(scene, W, H, S, passes, depth, limit=10, fast_px_budget=0.004
         wf = hf.render(W, H, S=S, passes=passes, seed=SEED, depth_limit=depth, rect=rect, threads=THREADS)[y:y + h, x:x + w, :3] / passes
         gf = fast[y:y + h, x:x + w, :3] / passes
         m = np.isfinite(gf) & np.isfinite(wf)
-        d = np.abs(gf - wf)[m]
+        # (relative where the radiance is above 1 -- the crops on the lights: FAST adds the passes of a launch in four groups,
+        # tests/test_hip_tail_parts.py, and one unit in the last place of a total of 300 is 3e-5)
+        d = (np.abs(gf - wf) / np.maximum(1.0, np.abs(wf)))[m]
         cl = np.where(m, np.clip(gf, 0, 1) - np.clip(wf, 0, 1), 0.0)
         off = int((np.abs(cl).max(-1) > 1e-3).sum())
         floor = (0.0, 0.0, 0.0, 0)
@@ -205,7 +207,7 @@ def test_configs1_spheres_1080p_16_passes(scenes, golden):
             g = got[y:y + h, x:x + w, :3] / 16
             m = np.isfinite(g) & np.isfinite(ref_s)
             rmse = np.sqrt(np.mean(((np.clip(g, 0, 1) - np.clip(ref_s, 0, 1)) ** 2)[m]))
-            assert np.median(np.abs(g - ref_s)[m]) <= 1e-5
+            assert np.median((np.abs(g - ref_s) / np.maximum(1.0, np.abs(ref_s)))[m]) <= 1e-5  # (relative above 1: the crops on the lights)
             assert rmse <= max(1e-3, scale * floor), (k, rmse, floor)
             if got is strict:
                 # BASELINE.json's figure, against the COMPILED REFERENCE (its -O2 build) on its own frame: per-pixel RMSE < 1e-4.

@@ -1369,7 +1369,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     __syncthreads();
 
     // per-wave mailbox for taken-over passes: [lane][stealWindow] float4, behind the scene copy (render_args.h)
-    DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.perWaveOffset + (threadIdx.x >> 6) * args.perWaveBytes);
+    // (the wave's index in its workgroup is the same in every lane: a scalar, not a vector register alive to the end of the kernel)
+    const uint32_t waveInGroup = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    DFloat4* mailbox = reinterpret_cast<DFloat4*>(ldsRaw + args.perWaveOffset + waveInGroup * args.perWaveBytes);
 
     // ---- which pixel is mine ----------------------------------------------------------------
     const int lane = threadIdx.x & 63;

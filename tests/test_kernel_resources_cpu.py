@@ -120,10 +120,9 @@ def test_exact_kernels_keep_their_register_budgets():
     instance carries the inline shadow walk and spills a few registers at that occupancy (measured: still the faster schedule)."""
     res, asm = _compile("exact")
     r = res["kajo_render_exact"]
-    # (since the launch tail came in parts -- integrator.inc.hip PARTS -- the compiler parks three values the code AFTER the loop needs
-    # in scratch across the loop: stored in the prologue, loaded behind the loop's exit, nothing in between; measured rate unchanged)
-    assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] <= 6 and r["ScratchSize"] <= 24 and r["SGPRs Spill"] <= 10, r
-    assert not _scratch_in_loops(asm, "kajo_render_exact")
+    assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["SGPRs Spill"] <= 10, r
+    # (the instance of any number of lights spills a few registers: none of them inside a loop)
+    assert not _scratch_in_loops(asm, "kajo_render_exact_split")
     r = res["kajo_render_exact_split"]
     assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] <= 3, r
     r = res["kajo_render_exact_lights"]

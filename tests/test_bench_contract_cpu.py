@@ -29,7 +29,9 @@ def test_fields_and_arithmetic():
     assert abs(achieved - r["achieved"]) / r["achieved"] < 1e-6
     assert r["kernel_ms_per_launch"] <= d["ms_per_step"]
     # HBM traffic from the PMC counters: present (collected on these very kernels) and close to the algorithmic 32 B per pixel
-    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["hbm"]["algorithmic_bytes_per_launch"] < 1.1
+    # (algorithmic: the tile buffer read and written once; on top, a parted launch writes its 2 560 cheapest blocks' three later
+    # groups to the side buffers -- 7.9 MB, half the dispatches the counters saw were parted -- and nothing else: no scratch)
+    assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["hbm"]["algorithmic_bytes_per_launch"] < 1.2
     c = d["cpu_baseline"]
     assert c["kind"] == "reference" and c["unit"] == "Msamples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["speedup_vs_cpu_baseline"] - d["value"] / c["value"]) < 1e-6 * d["speedup_vs_cpu_baseline"]

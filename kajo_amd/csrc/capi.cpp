@@ -599,6 +599,10 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     {
         const int wavesPerTile = (p.tileW / 8) * (p.tileH / 8);
         h->gridBlocks = (unsigned)((long long)h->nTilesOwned * wavesPerTile / h->wavesPerBlock);
+        if ((long long)h->nTilesOwned * wavesPerTile / h->wavesPerBlock >= (1ll << 28)) { // (render_args.h: an order word has 28 bits for the block)
+            destroy(h);
+            return fail(KAJO_E_INVALID, "frame too large: 2^28 pixel blocks per handle at most");
+        }
         if (h->gridBlocks && !(p.flags & KAJO_FLAG_NO_REORDER)) {
             CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->waveTrips), (size_t)h->gridBlocks * h->wavesPerBlock * sizeof(uint32_t)));
             CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->blockOrder), (size_t)h->gridBlocks * sizeof(uint32_t)));
@@ -694,7 +698,7 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         // (integrator.inc.hip GROUPS: the total takes the passes of this launch in four groups when they are 8, 16, 32 ...)
         // and the passes before it are whole groups of that size (pass numbers decide where a group ends: the same on every GPU of a frame)
         const bool quartered = now >= 8 && (now & (now - 1)) == 0 && h->passesDone % (now / 4) == 0;
-        a.groupPasses = quartered ? now / 4 : (1 << 30);
+        a.groupMask = quartered ? now / 4 - 1 : 0x7fffffff;
         hipEvent_t e0, e1;
         if ((rc = getEvent(h, &e0)) || (rc = getEvent(h, &e1)))
             return rc;

@@ -1335,7 +1335,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
 #endif
     // GROUPS (FAST / EXACT, small scenes): the pixel's total takes the passes of a launch in groups -- a quarter of the launch's passes each
-    // when they are 8, 16, 32 ... (args.groupPasses; else one group): every group is summed from zero in pass order, the group sums are
+    // when they are 8, 16, 32 ... (args.groupMask; else one group): every group is summed from zero in pass order, the group sums are
     // added to the total in group order. A sum any division of the launch's work can form: one wave rendering all passes of a pixel block
     // (the group sum in `total`, the running total in an LDS word of the lane), several waves dividing the passes (SPLIT: wave 0 adds
     // the terms of the table group by group), or -- PARTS, the launch tail (capi.cpp partTheTail) -- the cheapest blocks of a launch, the
@@ -1361,9 +1361,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             const int last = partFirst + partPasses;
             cam[0].w = __builtin_bit_cast(float, last);
             cam[1].w = __builtin_bit_cast(float, last - stealWindow > partFirst ? last - stealWindow : partFirst);
-            // a group ends before pass p when ((p - 1) & groupMask) == 0: groupPasses is a power of two, and the launch's first pass -- they
-            // are numbered from 1 -- begins a group (render_args.h)
-            cam[2].w = __builtin_bit_cast(float, args.groupPasses - 1);
+            // a group ends before pass p when ((p - 1) & groupMask) == 0: a group is a power of two of passes, and the launch's first pass --
+            // they are numbered from 1 -- begins one (render_args.h)
+            cam[2].w = __builtin_bit_cast(float, args.groupMask);
         }
     }
     __syncthreads();
@@ -2342,7 +2342,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         if (splitWave == 0 && inImage) {
             // (GROUPS: `group` is the sum of the group of passes p is in, `total` the total the complete groups have been added to)
             F3 group = f3(0.0f, 0.0f, 0.0f);
-            const int gMask = args.groupPasses - 1;
+            const int gMask = args.groupMask;
             for (int p = 0; p < args.nPasses; p++) { // Renderer.cpp:70-71, pass by pass
                 if (GROUPS && p > 0 && (p & gMask) == 0) {
                     total = total + group;

@@ -37,10 +37,11 @@ struct RenderArgs
     // passes), bits 28-29 = which part this workgroup is, bits 0-27 the block. Part k > 0 writes its sum to slot + k * sideStride: three
     // side buffers follow the tile buffer in the same allocation.
     uint32_t sideStride;          // slots per buffer; 0 unless the order holds parts
-    // FAST / EXACT kernels of small scenes (integrator.inc.hip GROUPS): passes per group of the pixel total's sum -- nPasses / 4 when
-    // nPasses is 8, 16, 32 ... and firstPass - 1 a multiple of it, else 2^30 (one group). A power of two: a group ends before pass p
-    // when ((p - 1) & (groupPasses - 1)) == 0. STRICT adds pass by pass and does not read it.
-    int32_t groupPasses;
+    // FAST / EXACT kernels of small scenes (integrator.inc.hip GROUPS): the passes of the launch enter a pixel's total in groups of
+    // groupMask + 1 passes -- nPasses / 4 when nPasses is 8, 16, 32 ... and firstPass - 1 a multiple of it: a group ends before pass p
+    // when ((p - 1) & groupMask) == 0 -- or in one group (groupMask 0x7fffffff: no pass number ends one). STRICT adds pass by pass and
+    // does not read it.
+    int32_t groupMask;
     // known-answer mode (kajo_hip_kat_shade): lane i runs ONE path from a given ray and RNG state
     const float* katRays;         // [katCount][6] origin, direction
     const uint64_t* katStates;    // [katCount][2]

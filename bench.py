@@ -194,6 +194,10 @@ def parity_leg(want, oracle_s, got, W, H, passes):
             "rmse_clamped01_without_worst_100_px": float(np.sqrt(sq[100:].sum() / cl.size)),
             "share_of_sq_error_in_worst_20_px": float(sq[:20].sum() / sq.sum()) if sq.sum() > 0 else None,
             "px_off_by_more_than_1e-3": int((np.abs(cl).max(-1) > 1e-3).sum()),
+            # the same over the LINEAR (unclamped) estimate -- the clamp hides every pixel brighter than 1, the lights above all -- and
+            # relative to the oracle's own magnitude (include/kajo_hip.h KAJO_EXACT_REL_TOL is a bound on the last figure for EXACT)
+            "rmse_linear": float(np.sqrt((np.where(m, g.astype(np.float64) - w, 0.0) ** 2).sum() / m.size)),
+            "max_rel_to_max_oracle_1e-3": float((np.abs(g - w) / np.maximum(np.abs(w), 1e-3))[m].max()),
             "nan_px": int(nan_g.sum()), "nan_px_oracle": int(nan_w.sum()), "nan_px_in_both": int((nan_g & nan_w).sum())}
 
 

@@ -54,7 +54,14 @@ extern "C" {
 #define KAJO_E_STATE (-4)     /* call not valid in the handle's current state */
 
 /* KajoParams.flags */
-#define KAJO_FLAG_STRICT 1u   /* strict numerics: bit-identical to the CPU oracle (slower) */
+#define KAJO_FLAG_FAST 0u     /* (the absence of KAJO_FLAG_STRICT and KAJO_FLAG_EXACT) fast numerics: hardware transcendentals, contracted
+                                   multiply-adds. The fastest build; it does NOT meet BASELINE's per-pixel RMSE < 1e-4 on spheres.json at
+                                   1920x1080 x 16 passes (6e-4: a few paths per million flip a hit / miss decision). Opt in by clearing
+                                   the flags kajo_hip_default_params sets. */
+#define KAJO_FLAG_STRICT 1u   /* strict numerics: bit-identical to the CPU oracle (slower). Like KAJO_FLAG_EXACT it forms the IEEE quotient
+                                   and square root of the closest-hit walk by hand, which is exact for operands of ordinary size only:
+                                   kajo_hip_create refuses a scene with a non-zero coordinate (object and camera transforms, radii) outside
+                                   2^-40 .. 2^40 in magnitude with KAJO_E_INVALID under either flag */
 #define KAJO_FLAG_COUNTERS 2u /* maintain device-side work counters */
 #define KAJO_FLAG_NO_GRID 4u  /* always walk every sphere (no uniform grid for large scenes) */
 #define KAJO_FLAG_NO_REORDER 8u /* dispatch workgroups in image order (no cost-sorted launch order) */
@@ -69,12 +76,17 @@ extern "C" {
                                    Scheduling only: the frame is the same bit for bit with and without */
 #define KAJO_FLAG_NO_SHADOW_LISTS 128u /* large scenes: shadow rays walk the uniform grid as extension rays do, instead of being answered
                                    from the lights' visibility lists inside the light loop (same results; for A/B runs and tests) */
-#define KAJO_FLAG_EXACT 512u  /* decision-exact numerics (round 5): the oracle's arithmetic (KAJO_FLAG_STRICT's) wherever a value can reach a
-                                   decision -- the closest-hit walk, hit points, normals, sampled directions, coins -- so every path meets the
-                                   oracle's objects, draws its random numbers and ends in its generator state; the fast forms where a value
-                                   only scales radiance (BSDF values and pdfs, the light pdf, MIS weights, throughput products). The buffer
-                                   differs from KAJO_FLAG_STRICT's in the last places of each path's radiance (and of the sums over the
-                                   passes: see kajo_hip_render). Not with KAJO_FLAG_STRICT. */
+#define KAJO_FLAG_EXACT 512u  /* decision-exact numerics (the default of kajo_hip_default_params): the oracle's arithmetic (KAJO_FLAG_STRICT's)
+                                   wherever a value can reach a decision -- the closest-hit walk, hit points, normals, sampled directions,
+                                   coins -- so every path meets the oracle's objects, draws its random numbers and ends in its generator
+                                   state; the fast forms where a value only scales radiance (BSDF values and pdfs, the light pdf, MIS
+                                   weights, throughput products). Tolerance against KAJO_FLAG_STRICT's (= the oracle's) buffer, asserted
+                                   by the whole-frame tests: the same pixels are not-a-number; every other pixel's sum differs by at most
+                                   KAJO_EXACT_REL_TOL of max(|oracle|, KAJO_EXACT_ABS_FLOOR * passes) per channel (measured: 9.2e-4 at
+                                   worst, where the oracle's light pdf 1 - cos(asin(r / d)) cancels); clamped per-pixel RMSE of the
+                                   estimate 6.5e-7 on spheres.json at 1920x1080 x 16 passes. Not with KAJO_FLAG_STRICT. */
+#define KAJO_EXACT_REL_TOL 1.5e-3f
+#define KAJO_EXACT_ABS_FLOOR 1e-3f
 #define KAJO_FLAG_NO_ONE_LIGHT 256u /* small scenes with exactly one light, every numerics build: run the kernel instance of any number of lights
                                    (kajo_render_*_lights) instead of the one that samples the BSDF in the light's visit (same results in the
                                    FAST and EXACT builds bit for bit and in the STRICT build, which stays the oracle; the hold thresholds
@@ -106,26 +118,25 @@ typedef struct KajoCounters {
     uint64_t shadowQueries;  /* large scenes: shadow rays answered from the lights' visibility lists inside the light loop (they
                                 are not among `traversals`, which then counts camera and extension rays only) */
     uint64_t tailGroups;     /* of the last render launch: workgroups beyond one per pixel block -- the cheapest blocks of a large frame
-                                of a small scene are rendered as four workgroups of a quarter of the passes each, so that the launch
-                                ends on short jobs (FAST / EXACT, launches of 8, 16, 32 ... passes; the frame is the same bit for bit;
+                                of a small scene are rendered as one workgroup per group of four passes of the launch, so that the launch
+                                ends on short jobs (FAST / EXACT, launches of 2 .. 8 whole groups; the frame is the same bit for bit;
                                 0 = not parted) */
 } KajoCounters;
 
 typedef struct KajoHip* kajo_hip_t;
 
-/* Fills *p with the reference's constants: S = 32, depth 8, seed 236367, one tile set. */
+/* Fills *p with the reference's constants -- S = 32, depth 8, seed 236367, one tile set -- and flags = KAJO_FLAG_EXACT: the fastest
+   numerics build that meets BASELINE's per-pixel RMSE < 1e-4 against the reference. */
 void kajo_hip_default_params(KajoParams* p);
 
 int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoParams* params, kajo_hip_t* out);
 int kajo_hip_destroy(kajo_hip_t h); /* NULL is accepted */
 
 /* Enqueue `passes` more passes (pass numbers continue from the handle's count, first = 1; at most 2^31 - 1 in all).
-   How the passes' terms radiance / S enter a pixel's total (Renderer.cpp:70-71): STRICT adds them one by one, as the reference does.
-   FAST and EXACT (small scenes) add the passes of one launch -- at most passesPerLaunch passes of a call -- group by group: a launch
-   of 8, 16, 32 ... passes that starts on a multiple of a quarter of its size is four groups, any other launch one; a group is summed
-   from zero in pass order and then added to the total. The same terms in another order of additions (last place of the total), chosen
-   so that the work of a launch can be divided -- among waves, workgroups (KajoCounters.tailGroups) or GPUs -- without changing a bit:
-   the frame depends on the sequence of render() calls, not on how the handle or a scheduler divided them. */
+   The frame after P passes is a function of the scene, the parameters and P alone -- not of how the passes were cut into render()
+   calls, launches (passesPerLaunch), workgroups or GPUs. STRICT adds the passes' terms radiance / S to a pixel's total one by one, as
+   the reference does (Renderer.cpp:70-71); FAST and EXACT (small scenes) add them in groups of four passes by absolute number
+   (1-4, 5-8, ...): a group is summed from zero in pass order, then added to the total; a group in progress is added last. */
 int kajo_hip_render(kajo_hip_t h, int passes);
 int kajo_hip_wait(kajo_hip_t h);
 /* Zero the accumulation and restart the pass numbering at 1. */
@@ -134,7 +145,8 @@ int kajo_hip_reset(kajo_hip_t h);
    `for (pass = 1;; pass++)`, Renderer.cpp:44, has no end). The call does not touch the accumulation buffer and DECLARES
    that it holds the sum of `passesDone` passes: kajo_hip_resolve_* divide by the pass count and kajo_hip_counters reports
    it, so the caller restores the buffer of the session being continued through kajo_hip_tile_buffer() first (or calls
-   kajo_hip_reset() and set_pass_count(0)). Pass numbers run to 2^31 - 2. */
+   kajo_hip_reset() and set_pass_count(0)). FAST / EXACT: a passesDone inside a group of four continues from the buffer as
+   one sum (the passes of the group so far are not known apart). Pass numbers run to 2^31 - 2. */
 int kajo_hip_set_pass_count(kajo_hip_t h, int passesDone);
 
 /* Whole-frame outputs; valid when tileCount == 1, or on a handle that has been composed.
@@ -190,6 +202,14 @@ typedef struct KajoStageInfo {
     float gridCenter[3], gridReach;
 } KajoStageInfo;
 int kajo_hip_stage_info(const KajoScene* scene, KajoStageInfo* out);
+
+/* Host-only helper (no GPU needed), for tests: the order a handle dispatches its workgroups in (kajo_amd/csrc/launch_order.h), from the
+   loop trips its first launch measured per wave -- waveTrips[nBlocks * wavesPerBlock] -- on a chip of `waveSlots` resident waves:
+   blocks by cost, the most expensive first, and -- parts = 2 .. 8, the groups of four passes of a launch of FAST / EXACT kernels of a
+   small scene -- the last *nParted (cheapest) blocks as `parts` consecutive workgroups of one group each. An order word is
+   block | part << 28 | parted << 31. Returns the number of words (order may be NULL to ask for it); negative = error. */
+int kajo_hip_launch_order(const uint32_t* waveTrips, uint32_t nBlocks, uint32_t wavesPerBlock, uint32_t waveSlots, int32_t parts, uint32_t* order,
+                          size_t capacity, uint32_t* nParted);
 
 /* Known-answer hooks: run the kernels' OWN device functions on caller-supplied rays, so that the
    vectors captured from the compiled reference (tests/golden/kat_trace.npz, kat_shade.npz) can be

@@ -20,6 +20,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # KAJO_HIP_LIB: a diagnostic twin of the library (e.g. the -DKAJO_PROFILE build of `make prof`); never a CPU path
 LIB_PATH = os.environ.get("KAJO_HIP_LIB") or os.path.join(_HERE, "libkajo_hip.so")
 
+KAJO_OK, KAJO_E_INVALID, KAJO_E_HIP, KAJO_E_NO_DEVICE, KAJO_E_STATE = 0, -1, -2, -3, -4
+
+KAJO_FLAG_FAST = 0  # (neither of the two below)
 KAJO_FLAG_STRICT = 1
 KAJO_FLAG_COUNTERS = 2
 KAJO_FLAG_NO_GRID = 4
@@ -38,6 +41,7 @@ EXPORTS = [
     "kajo_hip_tile_buffer", "kajo_hip_compose", "kajo_hip_set_stream", "kajo_hip_counters",
     "kajo_hip_stage_scene", "kajo_hip_last_error", "kajo_hip_version", "kajo_hip_kat_trace", "kajo_hip_kat_shade",
     "kajo_hip_kat_strictmath", "kajo_hip_stage_shadow_lists", "kajo_hip_resolve_gathered_argb8_device", "kajo_hip_stage_info",
+    "kajo_hip_launch_order",
 ]
 
 
@@ -110,6 +114,8 @@ def lib():
                                                       C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         if hasattr(L, "kajo_hip_stage_info"):
             L.kajo_hip_stage_info.argtypes = [C.POINTER(KajoScene), C.POINTER(KajoStageInfo)]
+        if hasattr(L, "kajo_hip_launch_order"):  # (round 6)
+            L.kajo_hip_launch_order.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int32, C.c_void_p, C.c_size_t, C.POINTER(C.c_uint32)]
         L.kajo_hip_kat_trace.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 8
         L.kajo_hip_kat_shade.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 5
         L.kajo_hip_kat_strictmath.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]

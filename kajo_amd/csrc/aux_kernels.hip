@@ -25,18 +25,18 @@ extern "C" int kajo_compose_launch(const void* gathered, const TileMap* map, voi
     return (int)hipGetLastError();
 }
 
-// Launch tail (integrator.inc.hip PARTS, capi.cpp partedOrder): blocks rendered in 2 or 4 parts have part 0's sum -- the pixel's total so
-// far plus its passes -- in `tiles` and the later parts' sums in the side buffers; the total is their sum in part order. One workgroup per
-// such block, `threads` = the render kernel's workgroup size (a block's slots are block * threads ...). Plain additions, no products: the
-// result does not depend on the contraction setting of this file.
-extern "C" __global__ void __launch_bounds__(256) kajo_fold_parts(float4* tiles, const float4* side, uint32_t sideStride, const uint32_t* blocks)
+// Launch tail (integrator.inc.hip PARTS, capi.cpp partTheTail): a block rendered in `parts` workgroups has part 0's sum -- the pixel's total
+// so far plus the launch's first group -- in `tiles` and the later groups' sums in the compact side buffers (sideStride slots each, the
+// j-th parted block's at j * blockDim.x); the total is their sum in group order. One workgroup per such block, `threads` = the render
+// kernel's workgroup size (a block's slots are block * threads ...). Plain additions, no products: the result does not depend on the
+// contraction setting of this file.
+extern "C" __global__ void __launch_bounds__(256) kajo_fold_parts(float4* tiles, const float4* side, uint32_t sideStride, const uint32_t* blocks, int parts)
 {
-    const uint32_t word = blocks[blockIdx.x];
-    const uint32_t slot = (word & 0x0fffffffu) * blockDim.x + threadIdx.x;
-    const int parts = 1 << (word >> 30);
+    const uint32_t slot = (blocks[blockIdx.x] & 0x0fffffffu) * blockDim.x + threadIdx.x;
+    const uint32_t sideSlot = blockIdx.x * blockDim.x + threadIdx.x;
     float4 t = tiles[slot];
     for (int k = 1; k < parts; k++) {
-        const float4 s = side[(size_t)(k - 1) * sideStride + slot];
+        const float4 s = side[(size_t)(k - 1) * sideStride + sideSlot];
         t.x += s.x;
         t.y += s.y;
         t.z += s.z;
@@ -44,9 +44,10 @@ extern "C" __global__ void __launch_bounds__(256) kajo_fold_parts(float4* tiles,
     tiles[slot] = t;
 }
 
-extern "C" int kajo_fold_parts_launch(void* tiles, const void* side, uint32_t sideStride, const uint32_t* blocks, unsigned count, unsigned threads, void* stream)
+extern "C" int kajo_fold_parts_launch(void* tiles, const void* side, uint32_t sideStride, const uint32_t* blocks, unsigned count, unsigned threads, int parts,
+                                      void* stream)
 {
     hipLaunchKernelGGL(kajo_fold_parts, dim3(count), dim3(threads), 0, static_cast<hipStream_t>(stream), static_cast<float4*>(tiles),
-                       static_cast<const float4*>(side), sideStride, blocks);
+                       static_cast<const float4*>(side), sideStride, blocks, parts);
     return (int)hipGetLastError();
 }

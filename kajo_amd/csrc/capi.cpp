@@ -20,7 +20,10 @@
 
 #include "render_args.h"
 #include "stage.h"
+#include "launch_order.h"
 #include "tuning.h"
+
+constexpr int kMaxParts = 8; // workgroups a block of the launch tail is rendered in: one per group of a launch of 2 .. 8 groups
 
 // launchers defined next to their kernels (kernel_fast.hip, kernel_strict.hip, kernel_exact.hip, aux_kernels.hip)
 extern "C" {
@@ -39,7 +42,7 @@ int kajo_resolve_strict_launch(const void* frame, int count, float passes, void*
 int kajo_resolve_tiles_fast_launch(const void* gathered, const TileMap* map, float passes, void* dst, void* stream);
 int kajo_resolve_tiles_strict_launch(const void* gathered, const TileMap* map, float passes, void* dst, void* stream);
 int kajo_compose_launch(const void* gathered, const TileMap* map, void* frame, void* stream);
-int kajo_fold_parts_launch(void* tiles, const void* side, uint32_t sideStride, const uint32_t* blocks, unsigned count, unsigned threads, void* stream);
+int kajo_fold_parts_launch(void* tiles, const void* side, uint32_t sideStride, const uint32_t* blocks, unsigned count, unsigned threads, int parts, void* stream);
 int kajo_kat_shade_fast_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_kat_shade_strict_launch(const RenderArgs*, unsigned grid, size_t lds, void* stream);
 int kajo_kat_trace_fast_launch(const KatTraceArgs*, unsigned grid, size_t lds, void* stream);
@@ -114,11 +117,18 @@ struct KajoHip
     uint32_t* blockOrder = nullptr;  // device [grid]
     bool orderValid = false, tripsPending = false;
     unsigned gridBlocks = 0;
-    // launch tail (updateBlockOrder): the same order with its cheapest blocks in 2 or 4 parts, the blocks that have parts, their side buffers
-    uint32_t* partedOrder = nullptr; // device [partedGrid]
-    uint32_t* partedBlocks = nullptr; // device [nParted]
-    unsigned partedGrid = 0, nParted = 0;
-    bool sideTiles = false;      // three side buffers follow `tiles` in its allocation (float4 [3][slotsPerOwner], zeroed with it)
+    // launch tail (updateBlockOrder / partTheTail): the cost-sorted order on the host, how many of its last (cheapest) blocks are rendered in
+    // parts, those blocks, and per number of parts G = 2 .. 8 the order with each of them expanded into G workgroups (built on first use)
+    std::vector<uint32_t> hostOrder;
+    uint32_t* partedOrder[kMaxParts + 1] = {}; // device [gridBlocks + (G - 1) * nParted]
+    uint32_t* partedBlocks = nullptr;               // device [nParted]
+    unsigned nParted = 0;
+    void* side = nullptr;        // float4 [kMaxParts - 1][nParted * block threads]: the later parts' group sums of one launch
+    bool partsAllowed = false;   // FAST / EXACT handle of a small scene that orders its launches and may divide them
+    // FAST / EXACT, small scenes (render_args.h): a launch that ends inside a group of four passes leaves the group so far and the total of
+    // the complete groups here
+    void* carry = nullptr;       // float4 [2][slotsPerOwner], on first need
+    bool carryValid = false;     // ... and they are those of passesDone
     int waveSlots = 0;           // waves the chip holds at once with this handle's kernel (updateBlockOrder)
     unsigned lastTailGroups = 0; // KajoCounters.tailGroups
     unsigned wavesPerBlock = 1; // workgroup = 64 * wavesPerBlock threads: single-wave groups dispatch and retire
@@ -259,13 +269,92 @@ void destroy(KajoHip* h)
         (void)hipFree(h->waveTrips);
     if (h->blockOrder)
         (void)hipFree(h->blockOrder);
-    if (h->partedOrder)
-        (void)hipFree(h->partedOrder);
+    for (uint32_t* o : h->partedOrder)
+        if (o)
+            (void)hipFree(o);
     if (h->partedBlocks)
         (void)hipFree(h->partedBlocks);
+    if (h->side)
+        (void)hipFree(h->side);
+    if (h->carry)
+        (void)hipFree(h->carry);
     if (h->ownStream && h->stream)
         (void)hipStreamDestroy(h->stream);
     delete h;
+}
+
+// The launch tail. Workgroups are dispatched in order as wave slots come free, so a launch ends while its last `waveSlots` jobs run out:
+// on average half such a job per slot stands idle -- 3 % of a 1920x1080 launch (six rounds of the slots), 1 % at 3840x2160. The cheapest
+// blocks, last in the order, are therefore rendered as one workgroup per GROUP of the launch's passes (integrator.inc.hip PARTS; a launch of
+// 16 passes: four workgroups of four passes): the launch ends on short jobs. Short waves are the less efficient ones (a lane that has run
+// out of passes can only take over whole ones: 16 -> 4 passes per wave costs 10 %, tools/ppl_sweep.py), so only the tail is parted. FAST
+// and EXACT kernels of small scenes, whose totals take the passes in groups of four whoever renders them (integrator.inc.hip GROUPS):
+// the frame does not change by a bit.
+// Which blocks: decided once, when the order is known. How they are expanded depends on the number of groups of a launch: partedOrderFor.
+int partTheTail(KajoHip* h)
+{
+    h->nParted = 0;
+    const unsigned n = (unsigned)h->hostOrder.size();
+    if (!h->partsAllowed || n >= (1u << 28))
+        return KAJO_OK;
+    if (!h->waveSlots) {
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
+        h->waveSlots = cus * 4 * (h->coldInLds ? 5 : 4); // (launch bounds of the small-scene / large-scene kernels)
+    }
+    int q4 = 4; // how many blocks, in eighths of the slots (measured: tools/tail_sweep.sh)
+    KAJO_TUNE_INT("KAJO_TAIL_Q4", 0, 64, q4);
+    const unsigned nParted = kajoTailBlocks(n, (unsigned)h->waveSlots / h->wavesPerBlock, q4);
+    if (nParted == 0)
+        return KAJO_OK;
+    const unsigned block = 64 * h->wavesPerBlock;
+    for (uint32_t*& o : h->partedOrder) {
+        if (o)
+            (void)hipFree(o);
+        o = nullptr;
+    }
+    if (h->partedBlocks)
+        (void)hipFree(h->partedBlocks);
+    if (h->side)
+        (void)hipFree(h->side);
+    h->partedBlocks = nullptr;
+    h->side = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->partedBlocks), (size_t)nParted * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(h->partedBlocks, h->hostOrder.data() + (n - nParted), (size_t)nParted * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // the later parts' group sums of one launch: compact, a workgroup's worth of slots per parted block and part (18 MB at 1920x1080)
+    HIP_TRY(hipMalloc(&h->side, (size_t)(kMaxParts - 1) * nParted * block * 16));
+    h->nParted = nParted;
+    return KAJO_OK;
+}
+
+// The order of a launch of `parts` groups: every block once, in cost order, the last nParted of them as `parts` consecutive workgroups.
+int partedOrderFor(KajoHip* h, int parts)
+{
+    if (h->partedOrder[parts])
+        return KAJO_OK;
+    std::vector<uint32_t> parted;
+    kajoPartedOrder(h->hostOrder, h->nParted, parts, parted);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->partedOrder[parts]), parted.size() * sizeof(uint32_t)));
+    HIP_TRY(hipMemcpy(h->partedOrder[parts], parted.data(), parted.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    return KAJO_OK;
+}
+
+// Longest-processing-time-first order of the workgroups from the trips the first launch recorded
+// (a block runs as long as its slowest wave).
+int updateBlockOrder(KajoHip* h)
+{
+    h->tripsPending = false;
+    const unsigned n = h->gridBlocks;
+    const unsigned w = h->wavesPerBlock;
+    std::vector<uint32_t> trips((size_t)n * w);
+    HIP_TRY(hipMemcpy(trips.data(), h->waveTrips, trips.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    std::vector<uint32_t> cost, order;
+    kajoBlockCosts(trips.data(), n, w, cost);
+    kajoCostOrder(cost, order);
+    HIP_TRY(hipMemcpy(h->blockOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+    h->orderValid = true;
+    h->hostOrder.swap(order);
+    return partTheTail(h);
 }
 
 } // namespace
@@ -293,6 +382,7 @@ void kajo_hip_default_params(KajoParams* p)
     p->tileIndex = 0;
     p->tileCount = 1;
     p->passesPerLaunch = 0;
+    p->flags = KAJO_FLAG_EXACT; // the fastest build that meets BASELINE's RMSE < 1e-4 against the reference (include/kajo_hip.h)
 }
 
 int kajo_hip_stage_scene(const KajoScene* scene, float* invDet17, float* basis12)
@@ -364,6 +454,31 @@ int kajo_hip_stage_info(const KajoScene* scene, KajoStageInfo* info)
     return KAJO_OK;
 }
 
+int kajo_hip_launch_order(const uint32_t* waveTrips, uint32_t nBlocks, uint32_t wavesPerBlock, uint32_t waveSlots, int32_t parts, uint32_t* order,
+                          size_t capacity, uint32_t* nPartedOut)
+{
+    if (!waveTrips || wavesPerBlock < 1 || wavesPerBlock > 4 || parts < 1 || parts > kMaxParts || nBlocks >= (1u << 28))
+        return fail(KAJO_E_INVALID, "invalid argument");
+    std::vector<uint32_t> cost, plain, out;
+    kajoBlockCosts(waveTrips, nBlocks, wavesPerBlock, cost);
+    kajoCostOrder(cost, plain);
+    const unsigned nParted = kajoTailBlocks(nBlocks, waveSlots / wavesPerBlock);
+    if (nPartedOut)
+        *nPartedOut = nParted;
+    if (parts >= 2 && nParted)
+        kajoPartedOrder(plain, nParted, parts, out);
+    else
+        out.swap(plain);
+    if (out.size() > 0x7fffffffu)
+        return fail(KAJO_E_INVALID, "order too long");
+    if (order) {
+        if (capacity < out.size())
+            return fail(KAJO_E_INVALID, "order array too small");
+        std::memcpy(order, out.data(), out.size() * sizeof(uint32_t));
+    }
+    return (int)out.size();
+}
+
 int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoParams* params, kajo_hip_t* out)
 {
     if (!scene || !params || !out)
@@ -394,6 +509,20 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         return fail(KAJO_E_INVALID, "tile size must be multiples of 8 with tileW*tileH a multiple of 256");
     if (p.tileCount < 1 || p.tileIndex < 0 || p.tileIndex >= p.tileCount)
         return fail(KAJO_E_INVALID, "tileIndex/tileCount out of range");
+
+    if (p.flags & (KAJO_FLAG_STRICT | KAJO_FLAG_EXACT)) {
+        // integrator.inc.hip kdiv / ksqrt: the IEEE quotient and root without the compiler's range scaling are exact while operands stay
+        // dozens of binades inside the float range, which a scene of ordinary coordinates guarantees; outside it STRICT would silently
+        // stop being the oracle
+        float lo = 0.f, hi = 0.f;
+        kajo::coordinateRange(*scene, &lo, &hi);
+        if (!(hi == hi) || (hi > 0.f && (lo < 0x1p-40f || hi > 0x1p40f))) {
+            char msg[256];
+            std::snprintf(msg, sizeof msg, "strict / exact numerics need the scene's non-zero coordinates within 2^-40 .. 2^40 in magnitude "
+                                           "(found %g .. %g): use the fast build or rescale the scene", (double)lo, (double)hi);
+            return fail(KAJO_E_INVALID, msg);
+        }
+    }
 
     int nDev = 0;
     hipError_t e = hipGetDeviceCount(&nDev);
@@ -488,7 +617,7 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
     // (integrator.inc.hip stageToLds: the 4-byte arrays are padded to a 16-byte boundary before the light records)
     const size_t hotBytes = (size_t)v.nPlanes * 16 + (size_t)v.nSphereHot * 16 +
                             ((((size_t)v.nPlanes + (v.allTranslated ? 0 : v.nSpheres) + v.nLights) * 4 + 15) & ~(size_t)15) + (size_t)v.nLights * (64 + 16) +
-                            ((((size_t)v.nLights * v.nPlanes) * 4 + 15) & ~(size_t)15) + 7 * 16;
+                            ((((size_t)v.nLights * v.nPlanes) * 4 + 15) & ~(size_t)15) + 8 * 16;
     const size_t coldBytes = (size_t)v.nPlanes * 48 + (size_t)v.nSpheres * 64 + (size_t)(v.nPlanes + v.nSpheres) * sizeof(DMaterial);
     // What every wave adds to the scene copy (render_args.h): the mailbox of taken-over passes.
     // The sizes below are constants of the product library. A -DKAJO_TUNING build (libkajo_hip_tune.so, tools/ only) reads
@@ -587,11 +716,10 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         h->nTilesOwned = 0;
     m.slotsPerOwner = h->tilesPerOwner * p.tileW * p.tileH;
     h->tileBytes = (size_t)m.slotsPerOwner * 16;
-    // (FAST / EXACT handles of small scenes that order their launches: room for the three side buffers of the launch tail behind the
-    // tile buffer, partTheTail; slots outside the image are never written and stay zero)
-    h->sideTiles = h->coldInLds && h->numerics() != 1 && !(p.flags & (KAJO_FLAG_NO_SPLIT | KAJO_FLAG_NO_REORDER)) && m.slotsPerOwner < (1 << 28);
-    CREATE_TRY(hipMalloc(&h->tiles, h->tileBytes * (h->sideTiles ? 4 : 1)));
-    CREATE_TRY(hipMemsetAsync(h->tiles, 0, h->tileBytes * (h->sideTiles ? 4 : 1), h->stream));
+    // (FAST / EXACT handles of small scenes that order their launches render the tail of a launch in parts: partTheTail)
+    h->partsAllowed = h->coldInLds && h->numerics() != 1 && !(p.flags & (KAJO_FLAG_NO_SPLIT | KAJO_FLAG_NO_REORDER));
+    CREATE_TRY(hipMalloc(&h->tiles, h->tileBytes));
+    CREATE_TRY(hipMemsetAsync(h->tiles, 0, h->tileBytes, h->stream));
     if (p.flags & KAJO_FLAG_COUNTERS) {
         CREATE_TRY(hipMalloc(reinterpret_cast<void**>(&h->counters), 32 * sizeof(unsigned long long)));
         CREATE_TRY(hipMemsetAsync(h->counters, 0, 32 * sizeof(unsigned long long), h->stream));
@@ -695,10 +823,19 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         const int now = left < perLaunch ? left : perLaunch;
         a.firstPass = h->passesDone + 1;
         a.nPasses = now;
-        // (integrator.inc.hip GROUPS: the total takes the passes of this launch in four groups when they are 8, 16, 32 ...)
-        // and the passes before it are whole groups of that size (pass numbers decide where a group ends: the same on every GPU of a frame)
-        const bool quartered = now >= 8 && (now & (now - 1)) == 0 && h->passesDone % (now / 4) == 0;
-        a.groupMask = quartered ? now / 4 - 1 : 0x7fffffff;
+        // (integrator.inc.hip GROUPS, FAST / EXACT kernels of small scenes: the total takes the passes in groups of four by their absolute
+        // numbers. A launch that begins or ends inside a group hands the group over through `carry`: render_args.h)
+        const bool grouped = h->coldInLds && h->numerics() != 1;
+        const bool startsInside = grouped && h->passesDone % KAJO_GROUP_PASSES != 0, endsInside = grouped && (h->passesDone + now) % KAJO_GROUP_PASSES != 0;
+        if ((startsInside || endsInside) && !h->carry)
+            HIP_TRY(hipMalloc(&h->carry, 2 * h->tileBytes));
+        a.carry = h->carry;
+        a.carrySlots = (uint32_t)h->map.slotsPerOwner;
+        // (a group whose first passes this handle did not render -- kajo_hip_set_pass_count to the middle of one -- continues from the
+        // buffer as it stands: the restored sum counts as complete groups)
+        a.carryIn = startsInside && h->carryValid;
+        a.carryOut = endsInside;
+        const int launchGroups = (!startsInside && !endsInside) ? now / KAJO_GROUP_PASSES : 0; // whole groups, or 0
         hipEvent_t e0, e1;
         if ((rc = getEvent(h, &e0)) || (rc = getEvent(h, &e1)))
             return rc;
@@ -767,17 +904,23 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         } else {
             // (coldInLds 2: the small-scene instance of any number of lights although the scene has one, KAJO_FLAG_NO_ONE_LIGHT)
             const int home = (h->coldInLds && (h->params.flags & KAJO_FLAG_NO_ONE_LIGHT)) ? 2 : h->coldInLds;
-            // the launch tail: the cheapest blocks in parts when the passes divide (updateBlockOrder)
-            const bool parted = h->orderValid && h->nParted && quartered;
+            // the launch tail: the cheapest blocks as one workgroup per group of the launch (partTheTail)
+            const bool parted = grouped && h->orderValid && h->nParted && launchGroups >= 2 && launchGroups <= kMaxParts;
             if (parted) {
-                h->lastTailGroups = h->partedGrid - grid;
+                if ((rc = partedOrderFor(h, launchGroups))) {
+                    h->eventPool.push_back(e0);
+                    h->eventPool.push_back(e1);
+                    return rc;
+                }
+                h->lastTailGroups = h->nParted * (unsigned)(launchGroups - 1);
                 RenderArgs b = a;
-                b.blockOrder = h->partedOrder;
-                b.sideStride = (uint32_t)h->map.slotsPerOwner;
-                le = (hipError_t)h->launchRender(&b, home, h->partedGrid, block, ldsTotal);
+                b.blockOrder = h->partedOrder[launchGroups];
+                b.side = h->side;
+                b.sideStride = h->nParted * block;
+                b.partedFirst = grid - h->nParted;
+                le = (hipError_t)h->launchRender(&b, home, grid + h->lastTailGroups, block, ldsTotal);
                 if (le == hipSuccess)
-                    le = (hipError_t)kajo_fold_parts_launch(h->tiles, static_cast<char*>(h->tiles) + h->tileBytes, b.sideStride, h->partedBlocks, h->nParted, block,
-                                                            h->stream);
+                    le = (hipError_t)kajo_fold_parts_launch(h->tiles, h->side, b.sideStride, h->partedBlocks, h->nParted, block, launchGroups, h->stream);
             } else {
                 le = (hipError_t)h->launchRender(&a, home, grid, block, ldsTotal);
             }
@@ -795,88 +938,12 @@ int kajo_hip_render(kajo_hip_t h, int passes)
         }
         h->launches++;
         h->passesDone += now;
+        h->carryValid = endsInside;
         left -= now;
     }
     h->frameValid = false;
     return KAJO_OK;
 }
-
-namespace
-{
-
-// The launch tail. Workgroups are dispatched in order as wave slots come free, so a launch ends while its last `waveSlots` jobs run out:
-// on average half such a job per slot stands idle -- 3 % of a 1920x1080 launch (six rounds of the slots), 1 % at 3840x2160. The cheapest
-// blocks, last in the order, are therefore rendered as FOUR workgroups of a quarter of the passes each (integrator.inc.hip PARTS): the
-// launch ends on short jobs. Short waves are the less efficient ones (a lane that has run out of passes can only take over whole ones:
-// 16 -> 4 passes per wave costs 10 %, tools/ppl_sweep.py), so only the tail is parted. FAST and EXACT kernels of small scenes, whose
-// totals take the passes of a launch in four groups whoever renders them (integrator.inc.hip GROUPS): the frame does not change by a bit.
-int partTheTail(KajoHip* h, const std::vector<uint32_t>& order)
-{
-    h->nParted = 0;
-    const unsigned n = (unsigned)order.size();
-    if (!h->sideTiles || n >= (1u << 28))
-        return KAJO_OK;
-    if (!h->waveSlots) {
-        int cus = 0;
-        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->device));
-        h->waveSlots = cus * 4 * (h->coldInLds ? 5 : 4); // (launch bounds of the small-scene / large-scene kernels)
-    }
-    const unsigned slots = (unsigned)h->waveSlots / h->wavesPerBlock;
-    // how many blocks, in eighths of the slots (measured: tools/tail_sweep.sh)
-    int q4 = 4;
-    KAJO_TUNE_INT("KAJO_TAIL_Q4", 0, 64, q4);
-    if (n < 2 * slots) // (frames of one or two rounds: the SPLIT kernels' business)
-        return KAJO_OK;
-    const unsigned n4 = std::min<unsigned>(n / 2, (unsigned)((unsigned long long)slots * q4 / 8));
-    const unsigned n2 = 0; // (halves would be another sum: the groups are quarters)
-    if (n4 + n2 == 0)
-        return KAJO_OK;
-    std::vector<uint32_t> parted, blocks;
-    parted.reserve(n + n2 + 3 * (size_t)n4);
-    for (unsigned i = 0; i < n; i++) {
-        const uint32_t partLog = i >= n - n4 ? 2u : (i >= n - n4 - n2 ? 1u : 0u);
-        for (uint32_t k = 0; k < (1u << partLog); k++)
-            parted.push_back(order[i] | (k << 28) | (partLog << 30));
-        if (partLog)
-            blocks.push_back(order[i] | (partLog << 30));
-    }
-    if (h->partedOrder)
-        (void)hipFree(h->partedOrder);
-    if (h->partedBlocks)
-        (void)hipFree(h->partedBlocks);
-    h->partedOrder = h->partedBlocks = nullptr;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->partedOrder), parted.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&h->partedBlocks), blocks.size() * sizeof(uint32_t)));
-    HIP_TRY(hipMemcpy(h->partedOrder, parted.data(), parted.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(h->partedBlocks, blocks.data(), blocks.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    h->partedGrid = (unsigned)parted.size();
-    h->nParted = (unsigned)blocks.size();
-    return KAJO_OK;
-}
-
-// Longest-processing-time-first order of the workgroups from the trips the first launch recorded
-// (a block runs as long as its slowest wave).
-int updateBlockOrder(KajoHip* h)
-{
-    h->tripsPending = false;
-    const unsigned n = h->gridBlocks;
-    const unsigned w = h->wavesPerBlock;
-    std::vector<uint32_t> trips((size_t)n * w);
-    HIP_TRY(hipMemcpy(trips.data(), h->waveTrips, trips.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    std::vector<uint32_t> cost(n), order(n);
-    for (unsigned b = 0; b < n; b++) {
-        cost[b] = 0;
-        for (unsigned k = 0; k < w; k++)
-            cost[b] = std::max(cost[b], trips[(size_t)w * b + k]);
-        order[b] = b;
-    }
-    std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cost[x] > cost[y]; });
-    HIP_TRY(hipMemcpy(h->blockOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
-    h->orderValid = true;
-    return partTheTail(h, order);
-}
-
-} // namespace
 
 int kajo_hip_wait(kajo_hip_t h)
 {

@@ -54,6 +54,12 @@
 
 #define KDEV __device__ __forceinline__
 typedef __attribute__((address_space(3))) volatile uint32_t KajoLdsWord; // a word of LDS that other lanes of the wave write
+// A float4 of global memory behind a pointer that waited in two LDS words (renderBody GROUPS): the address space spelled out -- a
+// pointer made from an integer is generic, and stores through it would be flat_store instructions.
+typedef float KajoVec4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) KajoVec4 KajoGlobalVec4;
+#define KAJO_GLOBAL_VEC4(lo, hi) \
+    ((KajoGlobalVec4*)((uint64_t)__builtin_bit_cast(uint32_t, lo) | ((uint64_t)__builtin_bit_cast(uint32_t, hi) << 32)))
 
 namespace
 {
@@ -242,9 +248,10 @@ struct LdsScene
     const DSphereCold* lightCold;  // [nLights] the lights' own cold records and
     const DFloat4* lightEmission;  // [nLights] emissions, always in LDS: a large scene's light loop reads nothing from global memory
     const float* lightPlaneSide;   // [nLights][nPlanes] +1 / -1: the light's whole ball lies on that side of the plane (by a margin); 0: it does not
-    const DFloat4* camera;         // [7] p1, p2 - p1, p3 - p1, origin (Renderer.cpp:29-34), background, the pixel / sample sizes of
+    const DFloat4* camera;         // [8] p1, p2 - p1, p3 - p1, origin (Renderer.cpp:29-34), background, the pixel / sample sizes of
                                    // Renderer.cpp:39-42, stream key words + W + H: read where a camera ray is formed /
-                                   // a ray escapes, instead of fifteen scalar registers held through the whole loop (the loop spills SGPRs)
+                                   // a ray escapes, instead of fifteen scalar registers held through the whole loop (the loop spills SGPRs);
+                                   // [7] and the .w words of [0..3]: what the end of the kernel needs of the launch (renderBody)
     const DFloat4* gridHeader;     // [5] (bmin, dim.x), (bmax, dim.y), (cell, dim.z), (1 / cell, -), (centre, reach^2): LDS, read at the start of a walk
     // The grid's cell lists, as staged into LDS when they fit (DGrid.inLds; else they are read from sc.grid's global arrays).
     // The two homes are kept in SEPARATE pointers and the walk is instantiated once per home: a pointer that may be either
@@ -1208,7 +1215,7 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
     const int np = sc.nPlanes, ns = sc.nSpheres;
     // layout: [planeRow np x16][sphereHot nHot x16]{[planeFrame 3np x16][sphereCold ns x64]
     //         [material (np+ns) x96]}[planeDet np x4][sphereHotOffset ns x4][light nL x4] (pad to 16)
-    //         [lightCold nL x64][lightEmission nL x16][lightPlaneSide nL*np x4 (pad to 16)][camera 7 x16]{[grid header 4 x16][grid cell starts][grid items]}
+    //         [lightCold nL x64][lightEmission nL x16][lightPlaneSide nL*np x4 (pad to 16)][camera 8 x16]{[grid header 4 x16][grid cell starts][grid items]}
     DFloat4* ldsPlaneRow = reinterpret_cast<DFloat4*>(ldsRaw);
     DFloat4* ldsSphereHot = ldsPlaneRow + np;
     DFloat4* cursor = ldsSphereHot + sc.nSphereHot;
@@ -1282,10 +1289,10 @@ KDEV LdsScene stageToLds(const DSceneView& sc, unsigned char* ldsRaw)
         cam4[3] = DFloat4{sc.origin[0], sc.origin[1], sc.origin[2], 0.0f};
         cam4[4] = DFloat4{sc.background[0], sc.background[1], sc.background[2], 0.0f};
     }
-    lds.camera = cam4; // (cam4[5], cam4[6] are the launch's, written by renderBody)
+    lds.camera = cam4; // (cam4[5 .. 7] are the launch's, written by renderBody)
     lds.lightCold = reinterpret_cast<const DSphereCold*>(lc4);
     lds.lightEmission = le4;
-    DFloat4* gh = cam4 + 7;
+    DFloat4* gh = cam4 + 8;
     lds.gridHeader = gh;
     if (!COLD_LDS && sc.grid.enabled && threadIdx.x == 0) {
         const DGrid& g = sc.grid;
@@ -1334,22 +1341,26 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #else
     const LdsScene lds = stageToLds<COLD_LDS>(sc, ldsRaw);
 #endif
-    // GROUPS (FAST / EXACT, small scenes): the pixel's total takes the passes of a launch in groups -- a quarter of the launch's passes each
-    // when they are 8, 16, 32 ... (args.groupMask; else one group): every group is summed from zero in pass order, the group sums are
-    // added to the total in group order. A sum any division of the launch's work can form: one wave rendering all passes of a pixel block
-    // (the group sum in `total`, the running total in an LDS word of the lane), several waves dividing the passes (SPLIT: wave 0 adds
-    // the terms of the table group by group), or -- PARTS, the launch tail (capi.cpp partTheTail) -- the cheapest blocks of a launch, the
-    // ones dispatched last, as FOUR workgroups of a quarter of the passes each, so that the launch ends on short jobs: part 0 adds its
-    // group to the total in the tile buffer, part k > 0 leaves its group's sum in side buffer k - 1, and a fold kernel adds the side
-    // buffers in part order after the launch. The frame does not depend on which blocks were parted, nor on how many GPUs shared it.
+    // GROUPS (FAST / EXACT, small scenes): the pixel's total takes the passes in groups of KAJO_GROUP_PASSES = 4 by their ABSOLUTE numbers
+    // (passes 1-4, 5-8, ...; render_args.h): every group is summed from zero in pass order, the group sums are added to the total in
+    // group order -- whatever launch, wave, workgroup or GPU renders a pass. A sum any division of the work can form: one wave rendering
+    // all passes of a pixel block (the group sum in `total`, the running total in an LDS word of the lane), several waves dividing the
+    // passes (SPLIT: wave 0 adds the terms of the table group by group), or -- PARTS, the launch tail (capi.cpp partTheTail) -- the
+    // cheapest blocks of a launch of G whole groups, the ones dispatched last, as G workgroups of one group each, so that the launch ends
+    // on short jobs: part 0 adds its group to the total in the tile buffer, part k > 0 leaves its group's sum in side buffer k - 1, and a
+    // fold kernel adds the side buffers in part order after the launch. A launch may begin and end inside a group: the group in progress
+    // and the total of the complete ones wait in args.carry between launches (the tile buffer holds their sum, the visible value).
+    // The frame is a function of the scene, the parameters and the number of passes done -- not of how they were cut into render calls.
     // Not in the STRICT build: the oracle adds the passes' terms one by one (Renderer.cpp:70-71), and a sum of group sums is not that sum.
     constexpr bool GROUPS = !KAT && !KAJO_RSTRICT && COLD_LDS;
     constexpr bool PARTS = GROUPS && !SPLIT;
+    constexpr int kGroupMask = KAJO_GROUP_PASSES - 1;
     const uint32_t orderWord = (!KAT && args.blockOrder) ? args.blockOrder[blockIdx.x] : blockIdx.x;
     const uint32_t logicalBlock = PARTS ? (orderWord & 0x0fffffffu) : orderWord;
-    const int partLog = PARTS ? (int)(orderWord >> 30) : 0, part = PARTS ? (int)((orderWord >> 28) & 3u) : 0;
+    const bool parted = PARTS && (orderWord >> 31) != 0u;
+    const int part = PARTS ? (int)((orderWord >> 28) & 7u) : 0; // (0 unless parted)
     const int stealWindow = args.stealWindow;
-    const int partPasses = args.nPasses >> partLog, partFirst = args.firstPass + part * partPasses;
+    const int partPasses = parted ? KAJO_GROUP_PASSES : args.nPasses, partFirst = args.firstPass + part * KAJO_GROUP_PASSES;
     if (threadIdx.x == 0) { // what only the camera-ray block needs of the launch: kept out of the scalar registers
         DFloat4* cam = const_cast<DFloat4*>(lds.camera);
         cam[5] = DFloat4{args.pixelWidth, args.pixelHeight, args.sampleWidth, args.sampleHeight};
@@ -1361,9 +1372,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             const int last = partFirst + partPasses;
             cam[0].w = __builtin_bit_cast(float, last);
             cam[1].w = __builtin_bit_cast(float, last - stealWindow > partFirst ? last - stealWindow : partFirst);
-            // a group ends before pass p when ((p - 1) & groupMask) == 0: a group is a power of two of passes, and the launch's first pass --
-            // they are numbered from 1 -- begins one (render_args.h)
-            cam[2].w = __builtin_bit_cast(float, args.groupMask);
+        }
+        // (GROUPS: where the pixel's sums go when the loop is over -- the tile buffer, or the side buffer of a later part; the carry of a
+        // launch that ends inside a group -- likewise: pointers in LDS words, not in scalar registers through the loop)
+        if (GROUPS) {
+            const uint64_t dst = reinterpret_cast<uint64_t>(part > 0 ? args.side : args.tiles), cry = args.carryOut ? reinterpret_cast<uint64_t>(args.carry) : 0ull;
+            cam[7] = DFloat4{__builtin_bit_cast(float, (uint32_t)dst), __builtin_bit_cast(float, (uint32_t)(dst >> 32)), __builtin_bit_cast(float, (uint32_t)cry),
+                             __builtin_bit_cast(float, (uint32_t)(cry >> 32))};
+            cam[2].w = __builtin_bit_cast(float, args.carrySlots);
         }
     }
     __syncthreads();
@@ -1378,9 +1394,12 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     const int splitWave = SPLIT ? (int)(threadIdx.x >> 6) : 0;
     const int splitCount = SPLIT ? (int)(blockDim.x >> 6) : 1;
     const uint32_t pixelSlot = SPLIT ? logicalBlock * 64u + (uint32_t)lane : logicalBlock * blockDim.x + threadIdx.x; // index into the tile buffer
-    // (part k > 0: the same slot of side buffer k - 1 -- the side buffers follow the tile buffer, sideStride slots each; nothing more to
-    // carry through the loop than the slot itself)
-    const uint32_t slot = PARTS ? pixelSlot + (uint32_t)part * args.sideStride : pixelSlot;
+    // (part k > 0: its slot of side buffer k - 1 -- the side buffers are compact, one workgroup's worth of slots per parted block in the
+    // order the blocks are parted in (render_args.h); nothing more to carry through the loop than the slot itself)
+    uint32_t slot = pixelSlot;
+    if (PARTS && part > 0) {
+        slot = kajoSideSlot(blockIdx.x, args.partedFirst, (uint32_t)(args.nPasses / KAJO_GROUP_PASSES), (uint32_t)part, args.sideStride, blockDim.x, threadIdx.x);
+    }
     // SPLIT: per-pass terms of the block, [nPasses][64] float4 behind the scene copy
     DFloat4* termTable = reinterpret_cast<DFloat4*>(ldsRaw + args.mailboxOffset);
     const int wave = (int)(pixelSlot >> 6);
@@ -1411,10 +1430,18 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     DFloat4* const accWord = mailbox + 64 * stealWindow + lane;
     if (PARTS) {
         if (inImage) {
-            const float4 t = part == 0 ? reinterpret_cast<const float4*>(args.tiles)[slot] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (args.carryIn) { // the launch continues a group: the complete groups' total and the group so far (never a parted launch)
+                t = reinterpret_cast<const float4*>(args.carry)[slot];
+                const float4 g = reinterpret_cast<const float4*>(args.carry)[args.carrySlots + slot];
+                total = f3(g.x, g.y, g.z);
+            } else if (part == 0) {
+                t = reinterpret_cast<const float4*>(args.tiles)[slot];
+            }
             *accWord = DFloat4{t.x, t.y, t.z, t.w};
         }
     } else if (!KAT && !LISTS_RMW && inImage) {
+        // (SPLIT kernels of the GROUPS builds: wave 0 re-reads what it needs after the loop)
         const float4 t = reinterpret_cast<const float4*>(args.tiles)[slot];
         total = f3(t.x, t.y, t.z);
         totalW = t.w;
@@ -1579,7 +1606,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     ownPass++;
                     if (PARTS) { // a group of passes complete
                         // (also when it was the last group: what is added after the loop is a zero then)
-                        if (((ownPass - 1) & __builtin_bit_cast(int, lds.camera[2].w)) == 0) {
+                        if (((ownPass - 1) & kGroupMask) == 0) { // (a group ends before pass p when (p - 1) % 4 == 0: passes are numbered from 1)
                             const DFloat4 a = *accWord;
                             *accWord = DFloat4{a.x + total.x, a.y + total.y, a.z + total.z, a.w};
                             total = f3(0.0f, 0.0f, 0.0f);
@@ -2342,9 +2369,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         if (splitWave == 0 && inImage) {
             // (GROUPS: `group` is the sum of the group of passes p is in, `total` the total the complete groups have been added to)
             F3 group = f3(0.0f, 0.0f, 0.0f);
-            const int gMask = args.groupMask;
+            if (GROUPS && args.carryIn) {
+                const float4 t = reinterpret_cast<const float4*>(args.carry)[slot], g = reinterpret_cast<const float4*>(args.carry)[args.carrySlots + slot];
+                total = f3(t.x, t.y, t.z);
+                totalW = t.w;
+                group = f3(g.x, g.y, g.z);
+            }
             for (int p = 0; p < args.nPasses; p++) { // Renderer.cpp:70-71, pass by pass
-                if (GROUPS && p > 0 && (p & gMask) == 0) {
+                if (GROUPS && ((args.firstPass + p - 1) & kGroupMask) == 0) { // pass firstPass + p begins a group (a zero is added where the launch begins one)
                     total = total + group;
                     group = f3(0.0f, 0.0f, 0.0f);
                 }
@@ -2369,8 +2401,15 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 else
                     total = total + term;
             }
-            if (GROUPS)
+            if (GROUPS) {
+                const DFloat4 c7 = lds.camera[7];
+                KajoGlobalVec4* const carry = KAJO_GLOBAL_VEC4(c7.z, c7.w);
+                if (carry) { // the launch ends inside a group
+                    carry[slot] = KajoVec4{total.x, total.y, total.z, totalW};
+                    carry[__builtin_bit_cast(uint32_t, lds.camera[2].w) + slot] = KajoVec4{group.x, group.y, group.z, 0.0f};
+                }
                 total = total + group;
+            }
             reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
         }
     } else if (!KAT && inImage) {
@@ -2381,25 +2420,32 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
         // passes of this pixel that other lanes rendered, in pass order
         if (PARTS) {
-            const int gMask = __builtin_bit_cast(int, lds.camera[2].w);
             DFloat4 a = *accWord;
             for (int p = myEnd; p < lastPass; p++) {
-                if (p > myEnd && ((p - 1) & gMask) == 0) { // (a group that ended with the lane's own last pass is in the word already)
+                if (p > myEnd && ((p - 1) & kGroupMask) == 0) { // (a group that ended with the lane's own last pass is in the word already)
                     a = DFloat4{a.x + total.x, a.y + total.y, a.z + total.z, a.w};
                     total = f3(0.0f, 0.0f, 0.0f);
                 }
                 const DFloat4 t = mailbox[lane * stealWindow + (p - stealBase)];
                 total = total + f3(t.x, t.y, t.z);
             }
-            total = f3(a.x + total.x, a.y + total.y, a.z + total.z); // the last group (a zero if the lane rendered its last pass itself)
+            const DFloat4 c7 = lds.camera[7];
+            KajoGlobalVec4* const carry = KAJO_GLOBAL_VEC4(c7.z, c7.w);
+            if (carry) { // the launch ends inside a group (never a parted launch): its two summands wait for the next launch
+                carry[slot] = KajoVec4{a.x, a.y, a.z, a.w};
+                carry[__builtin_bit_cast(uint32_t, lds.camera[2].w) + slot] = KajoVec4{total.x, total.y, total.z, 0.0f};
+            }
+            total = f3(a.x + total.x, a.y + total.y, a.z + total.z); // the last group (a zero if it ended with a pass the lane rendered itself)
             totalW = a.w;
+            // (the tile buffer, or the side buffer of a later part)
+            KAJO_GLOBAL_VEC4(c7.x, c7.y)[slot] = KajoVec4{total.x, total.y, total.z, totalW};
         } else {
             for (int p = myEnd; p < lastPass; p++) {
                 const DFloat4 t = mailbox[lane * stealWindow + (p - stealBase)];
                 total = total + f3(t.x, t.y, t.z);
             }
+            reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
         }
-        reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
     }
 #undef lastPass
 #undef stealBase

@@ -6,6 +6,8 @@
 
 #include "device_scene.h"
 
+#define KAJO_GROUP_PASSES 4 // passes per group of the FAST / EXACT totals (a power of two)
+
 struct RenderArgs
 {
     DSceneView scene;
@@ -33,15 +35,24 @@ struct RenderArgs
     // workgroups. Pure scheduling: the buffer slot of a pixel does not depend on it.
     const uint32_t* blockOrder;   // [grid] logical block run by physical block i; null = identity
     uint32_t* waveTrips;          // [grid * 4] loop trips of every wave of the launch; null = not recorded
-    // Launch tail: bits 30-31 of an order word = log2 of the parts its block is rendered in (0: one workgroup renders all nPasses
-    // passes), bits 28-29 = which part this workgroup is, bits 0-27 the block. Part k > 0 writes its sum to slot + k * sideStride: three
-    // side buffers follow the tile buffer in the same allocation.
-    uint32_t sideStride;          // slots per buffer; 0 unless the order holds parts
-    // FAST / EXACT kernels of small scenes (integrator.inc.hip GROUPS): the passes of the launch enter a pixel's total in groups of
-    // groupMask + 1 passes -- nPasses / 4 when nPasses is 8, 16, 32 ... and firstPass - 1 a multiple of it: a group ends before pass p
-    // when ((p - 1) & groupMask) == 0 -- or in one group (groupMask 0x7fffffff: no pass number ends one). STRICT adds pass by pass and
-    // does not read it.
-    int32_t groupMask;
+    // FAST / EXACT kernels of small scenes (integrator.inc.hip GROUPS): a pixel's total takes the passes in GROUPS of four by their ABSOLUTE
+    // numbers -- passes 1-4, 5-8, ... (KAJO_GROUP_PASSES): every group is summed from zero in pass order, the group sums are added to the
+    // total in group order. The frame after P passes is therefore a function of (scene, parameters, P) alone, however the passes were cut
+    // into launches, waves, workgroups or GPUs. A launch that ends inside a group leaves the visible sum (complete groups + the partial
+    // group) in `tiles` and the two summands in `carry`, where the launch that continues the group picks them up. STRICT adds pass by
+    // pass (Renderer.cpp:70-71) and reads none of this.
+    void* carry;                  // float4 [2][carrySlots]: the total of the complete groups, the sum of the group in progress; null unless
+    uint32_t carrySlots;          // carryIn or carryOut
+    int32_t carryIn;              // the launch starts inside a group whose first passes are in `carry`
+    int32_t carryOut;             // the launch ends inside a group: write `carry`
+    // Launch tail (capi.cpp partTheTail): the cheapest blocks of a launch of G = 2 .. 8 whole groups, last in the order, are rendered as G
+    // workgroups of one group each. Order word: bit 31 = the block is parted, bits 28-30 = which group of the launch this workgroup
+    // renders, bits 0-27 the block. Part 0 adds its group to the total in `tiles`; part k > 0 leaves its group's sum in side buffer
+    // k - 1, and a fold kernel adds the side buffers in order after the launch. Side buffers are compact: sideStride slots each, the
+    // slots of the j-th parted block of the order (physical blocks partedFirst + j * G ...) at j * blockDim.x.
+    void* side;                   // float4 [G - 1][sideStride]
+    uint32_t sideStride;          // slots per side buffer; 0 unless the order holds parts
+    uint32_t partedFirst;         // physical index of the first workgroup of a parted block
     // known-answer mode (kajo_hip_kat_shade): lane i runs ONE path from a given ray and RNG state
     const float* katRays;         // [katCount][6] origin, direction
     const uint64_t* katStates;    // [katCount][2]
@@ -81,6 +92,17 @@ static inline void kajoTileSlot(const TileMap& m, int x, int y, int* owner, uint
     const int lane = ((iy & 7) << 3) | (ix & 7);
     *owner = tile % m.tileCount;
     *slot = (uint32_t)(((tile / m.tileCount) * wavesPerTile + wb) * 64 + lane);
+}
+
+// Launch tail: slot of thread `tid` of physical workgroup `physical` -- part `part` > 0 of a parted block -- in the compact side buffers
+// (RenderArgs::side): buffer part - 1, behind the slots of the parted blocks before it in the order. The fold kernel reads the same
+// place as (part - 1) * sideStride + j * threads + tid for the j-th parted block.
+#if defined(__HIPCC__)
+__host__ __device__
+#endif
+static inline uint32_t kajoSideSlot(uint32_t physical, uint32_t partedFirst, uint32_t nParts, uint32_t part, uint32_t sideStride, uint32_t threads, uint32_t tid)
+{
+    return (part - 1u) * sideStride + ((physical - partedFirst) / nParts) * threads + tid;
 }
 
 #endif

@@ -633,6 +633,35 @@ void buildShadowLists(const KajoScene& s, StagedScene& out, bool wanted)
 
 } // namespace
 
+void coordinateRange(const KajoScene& s, float* lo, float* hi)
+{
+    float mn = 0.f, mx = 0.f;
+    bool bad = false;
+    auto see = [&](float v) {
+        const float a = std::fabs(v);
+        if (!(a == a) || std::isinf(a)) {
+            bad = true;
+            return;
+        }
+        if (a == 0.f)
+            return;
+        mn = (mx == 0.f || a < mn) ? a : mn;
+        mx = a > mx ? a : mx;
+    };
+    for (int i = 0; i < s.nPlanes; i++)
+        for (float v : s.planes[i].transform)
+            see(v);
+    for (int i = 0; i < s.nSpheres; i++) {
+        for (float v : s.spheres[i].transform)
+            see(v);
+        see(s.spheres[i].radius);
+    }
+    for (float v : s.camera.transform)
+        see(v);
+    *lo = mn;
+    *hi = bad ? std::nanf("") : mx;
+}
+
 void stageScene(const KajoScene& s, StagedScene& out, int gridMinSpheres, bool shadowLists)
 {
     out = StagedScene();

@@ -48,6 +48,11 @@ struct StagedScene
 
 void stageScene(const KajoScene& scene, StagedScene& out, int gridMinSpheres = 48, bool shadowLists = true);
 
+// Smallest and largest magnitude among the scene's non-zero, finite coordinates -- the elements of the object and camera (view) transforms and
+// the sphere radii; (0, 0) if there is none; a NaN or infinite coordinate makes *hi NaN. What kajo_hip_create holds against the range the
+// STRICT / EXACT kernels' hand-made IEEE quotient and square root are exact in (integrator.inc.hip kdiv, ksqrt).
+void coordinateRange(const KajoScene& scene, float* lo, float* hi);
+
 } // namespace kajo
 
 #endif

@@ -280,6 +280,7 @@ void Scheduler::run()
     // launch. With a preview: a 30 Hz refresh. Headless: half a second (the 1000-sphere scene at 4K takes 37 ms per pass: 13
     // passes per launch instead of 16, where round 4 launched 16 regardless -- 0.6 s -- and 32 in the tools: 1.2 s).
     double msPerPass = 0.0;
+    int samples = 0; // batches measured so far
     auto autoBatch = [&]() {
         if (o.passesPerUpdate > 0)
             return o.passesPerUpdate;
@@ -287,11 +288,11 @@ void Scheduler::run()
             return d.preview ? 1 : 2; // nothing measured yet
         const int fit = (int)((d.preview ? 33.0 : 500.0) / msPerPass);
         if (fit >= 8) {
-            // launches of 8 or 16 passes that start on a multiple of a quarter of their size: the FAST / EXACT kernels then render the
-            // cheapest blocks of a large frame in four parts (include/kajo_hip.h KajoCounters.tailGroups: +2 % at 1920x1080); a shorter
-            // batch first if the passes done so far do not end a group
-            const int size = fit >= 16 ? 16 : 8, group = size / 4, over = done % group;
-            return over ? group - over : size;
+            // launches of 8 or 16 passes that begin with a group of four (include/kajo_hip.h kajo_hip_render): the FAST / EXACT kernels then
+            // render the cheapest blocks of a large frame as one workgroup per group (KajoCounters.tailGroups: +2 % at 1920x1080); a shorter
+            // batch first if the passes done so far end inside a group. Scheduling only: the frame does not depend on the batches.
+            const int over = done % 4;
+            return over ? 4 - over : (fit >= 16 ? 16 : 8);
         }
         return fit < 1 ? 1 : fit;
     };
@@ -311,8 +312,11 @@ void Scheduler::run()
         const double batchWall = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb).count();
         batchMs.push_back(batchWall);
         batchPasses.push_back(now);
+        // (the first batch pays for the cold start -- module load, the blocks' cost measurement and its order: it sizes the second batch and
+        // is then forgotten)
         const double ms = batchWall / now;
-        msPerPass = msPerPass <= 0.0 ? ms : 0.75 * msPerPass + 0.25 * ms;
+        msPerPass = samples < 2 ? ms : 0.75 * msPerPass + 0.25 * ms;
+        samples++;
         if (d.preview)
             for (int p = done - now + 1; p <= done; p++)
                 d.preview->update(self, p, o.samplesPerPass, 0, 0, d.image->width, d.image->height);

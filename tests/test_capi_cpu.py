@@ -62,6 +62,43 @@ def test_argument_validation(scenes):
         assert e.value.code == -1, (kw, str(e.value))
 
 
+def test_default_params_select_the_build_that_meets_the_north_star():
+    """kajo_hip_default_params: the reference's constants (Renderer.cpp:21, Shader.cpp:24, Random.h:43) and EXACT numerics -- the fastest
+    build whose frame stays within BASELINE's per-pixel RMSE < 1e-4 of the reference; FAST is an explicit choice (flags = KAJO_FLAG_FAST)."""
+    p = capi.KajoParams()
+    capi.lib().kajo_hip_default_params(C.byref(p))
+    assert (p.samplesPerPass, p.depthLimit, p.seed, p.tileW, p.tileH, p.tileCount) == (32, 8, 0o715517, 64, 16, 1)
+    assert p.flags == capi.KAJO_FLAG_EXACT and capi.KAJO_FLAG_FAST == 0
+    header = open(os.path.join(ROOT, "include", "kajo_hip.h")).read()
+    assert re.search(r"#define KAJO_EXACT_REL_TOL 1\.5e-3f", header) and re.search(r"#define KAJO_EXACT_ABS_FLOOR 1e-3f", header)
+
+
+def test_scene_outside_the_exact_range_of_the_hand_made_division_is_refused(scenes):
+    """STRICT / EXACT form the IEEE quotient and square root of the closest-hit walk without the compiler's range scaling
+    (integrator.inc.hip kdiv / ksqrt): exact for scenes whose non-zero coordinates lie in 2^-40 .. 2^40, which kajo_hip_create checks --
+    before it looks for a device, so the refusal is testable here. The reference divides in hardware (Raytracer.cpp:30-44) and has no
+    such limit; FAST has none either."""
+    import copy
+    sc = scenes["spheres_a169"]
+    for scale, bad in ((2.0 ** 50, True), (2.0 ** -50, True), (2.0 ** 30, False), (float("nan"), True)):
+        moved = copy.deepcopy(sc)
+        moved.spheres = sc.spheres.copy()
+        moved.spheres[0, 12] = scale  # x of the first sphere's translation (column-major transform)
+        for kw in (dict(strict=True), dict(exact=True)):
+            with pytest.raises(capi.KajoError) as e:
+                HipRenderer(moved, 16, 16, **kw)
+            # (no GPU here: an accepted scene goes on to fail on the missing device)
+            import torch
+            if bad:
+                assert e.value.code == capi.KAJO_E_INVALID and "2^-40 .. 2^40" in str(e.value), (scale, kw, str(e.value))
+            elif not torch.cuda.is_available():
+                assert e.value.code == capi.KAJO_E_NO_DEVICE, (scale, kw, str(e.value))
+        if not torch.cuda.is_available():
+            with pytest.raises(capi.KajoError) as e:
+                HipRenderer(moved, 16, 16)  # FAST: no restriction
+            assert e.value.code == capi.KAJO_E_NO_DEVICE
+
+
 def test_no_cpu_fallback(scenes):
     """Without a GPU the product must fail loudly, not render on the CPU."""
     import torch

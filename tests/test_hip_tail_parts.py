@@ -1,12 +1,13 @@
 """The launch tail (kajo_amd/csrc/capi.cpp partTheTail, integrator.inc.hip GROUPS / PARTS, aux_kernels.hip kajo_fold_parts).
 
 From the second launch on -- the first measures the blocks -- the FAST and EXACT builds render the cheapest blocks of a large frame of
-a small scene as FOUR workgroups of a quarter of the launch's passes each, so that the launch ends on short jobs (+2 % at 1920x1080,
-profiles/r05_notes.txt). That must not change a bit of the frame: in these builds the pixel's total takes the passes of a launch of
-8, 16, 32 ... passes in four groups -- each summed from zero in pass order, the group sums added in group order -- whoever renders them:
-one wave all of them, several waves of a small frame dividing the passes (the SPLIT kernels), or the four workgroups of a parted block.
-So the frame does not depend on which blocks were parted, on the launch order, or on how many GPUs shared the frame. STRICT adds the
-passes' terms one by one, as the oracle does (Renderer.cpp:70-71), and is never parted."""
+a small scene as one workgroup per GROUP of four passes of the launch (a launch of 16 passes: four workgroups of four passes), so that
+the launch ends on short jobs (+2 % at 1920x1080, profiles/r05_notes.txt). That must not change a bit of the frame: in these builds the
+pixel's total takes the passes in groups of four by their absolute numbers -- each summed from zero in pass order, the group sums added
+in group order -- whoever renders them: one wave all of them, several waves of a small frame dividing the passes (the SPLIT kernels), or
+the workgroups of a parted block. So the frame does not depend on which blocks were parted, on the launch order, on how many GPUs shared
+the frame, or on how the passes were cut into launches (tests/test_hip_pass_cuts.py). STRICT adds the passes' terms one by one, as the
+oracle does (Renderer.cpp:70-71), and is never parted."""
 import numpy as np
 import pytest
 
@@ -36,6 +37,7 @@ def test_parted_tail_does_not_change_a_bit(scenes, mode):
     a, g = launches(sc, (16, 16, 8), **kw)
     assert g[0] == 0 and g[1] > 0 and g[2] > 0, g  # the first launch has no measured order yet
     assert g[1] % 3 == 0 and 1000 <= g[1] // 3 <= 14400 // 2  # three more workgroups for every parted block
+    assert g[2] == g[1] // 3  # (8 passes: two groups, one more workgroup per parted block)
     b, g0 = launches(sc, (16, 16, 8), flags=capi.KAJO_FLAG_NO_SPLIT, **kw)
     assert g0 == [0, 0, 0]
     assert np.array_equal(a, b, equal_nan=True)
@@ -57,11 +59,16 @@ def test_small_frames_divided_among_waves_form_the_same_sums(scenes, mode):
 
 
 def test_groups_are_sums_of_the_same_terms(scenes):
-    """What the groups may change against adding pass by pass: the order of float additions. The EXACT frame of 16 passes in one launch
-    (four groups) against the same 16 passes in launches of 2 (each launch one group: pass by pass up to a zero added first)."""
+    """What the groups change against adding pass by pass: the order of float additions, nothing else. EXACT's 16-pass frame against the
+    float64 sum of its sixteen passes' own terms (each rendered alone into a zeroed buffer)."""
     sc = scenes["spheres_a169"]
-    a, _ = launches(sc, (16,), w=320, h=180, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT)
-    b, _ = launches(sc, (2,) * 8, w=320, h=180, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT)
+    with HipRenderer(sc, 320, 180, seed=SEED, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT) as r:
+        a = r.render(16).radiance()[..., :3].copy()
+        b = np.zeros(a.shape, np.float64)
+        for p in range(16):
+            r.reset()
+            r.set_pass_count(p)
+            b += r.render(1).radiance()[..., :3]
     ok = np.isfinite(b).all(-1)
     assert np.array_equal(ok, np.isfinite(a).all(-1))
     rel = np.abs(a - b)[ok] / np.maximum(np.abs(b[ok]), 1e-3)
@@ -79,15 +86,27 @@ def test_strict_is_never_parted(scenes):
     assert np.array_equal(a, c, equal_nan=True)
 
 
-def test_only_launches_of_8_16_32_passes_on_a_group_boundary_are_parted(scenes):
-    """Groups are quarters of a launch of 8, 16, 32 ... passes that starts where a group of its size would (pass numbers decide where a
-    group ends, so that every GPU of a frame forms the same sums); any other launch is one group, rendered whole."""
+def test_only_launches_of_whole_groups_are_parted(scenes):
+    """A launch is parted when it is two to eight whole groups of four passes (pass numbers decide where a group ends, so that every GPU of
+    a frame forms the same sums); a launch that begins or ends inside a group, or is one group, is rendered whole."""
     sc = scenes["spheres_a169"]
-    seq = (8, 6, 2, 16, 12, 4, 16, 6, 16)  # passes done before each: 0, 8, 14, 16, 32, 44, 48, 64, 70
-    a, g = launches(sc, seq, exact=True)
-    assert [x > 0 for x in g] == [False, False, False, True, False, False, True, False, False], g
-    b, _ = launches(sc, seq, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT)
+    seq = (8, 6, 2, 16, 12, 4, 16, 6, 16, 2, 36)  # passes done before each: 0, 8, 14, 16, 32, 44, 48, 64, 70, 86, 88
+    with HipRenderer(sc, W, H, seed=SEED, passes_per_launch=64, exact=True) as r:
+        g = []
+        for p in seq:
+            r.render(p).wait()
+            g.append(r.counters()["tailGroups"])
+        a = r.radiance()[..., :3].copy()
+    assert [x > 0 for x in g] == [False, False, False, True, True, False, True, False, False, False, False], g
+    assert g[3] % 3 == 0 and g[4] == g[3] // 3 * 2  # one more workgroup per parted block and group beyond the first
+    with HipRenderer(sc, W, H, seed=SEED, passes_per_launch=64, exact=True, flags=capi.KAJO_FLAG_NO_SPLIT) as r:
+        for p in seq:
+            r.render(p)
+        b = r.radiance()[..., :3].copy()
     assert np.array_equal(a, b, equal_nan=True)
+    with HipRenderer(sc, W, H, seed=SEED, passes_per_launch=64, exact=True) as r:
+        c = r.render(sum(seq)).radiance()[..., :3].copy()  # 124 passes: 64 (16 groups: whole) + 60
+    assert np.array_equal(a, c, equal_nan=True)
 
 
 def test_large_scenes_are_not_parted(scenes):

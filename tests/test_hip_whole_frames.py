@@ -15,6 +15,7 @@ from kajo_amd.renderer import HipRenderer
 from kajo_amd.scene import Scene, stress_scene
 from oraclelib import OracleLib, available
 from scenes_extra import mixed_scene
+from exact_tol import assert_exact_within_tolerance
 from test_hip_workloads import SEED, clamped_rmse, record
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not available("oracle"), reason="oracle not built")]
@@ -51,10 +52,12 @@ def test_whole_frame_strict_is_the_oracle_and_exact_decides_as_it_does(scenes, n
         ex = r.render(P).radiance()
     nan_e = ~np.isfinite(ex[..., :3]).all(-1)
     assert np.array_equal(nan_e, nan_w), "%s: EXACT has %d not-a-number pixels, the oracle %d" % (name, int(nan_e.sum()), int(nan_w.sum()))
+    tol = assert_exact_within_tolerance(ex, want, P, name)  # include/kajo_hip.h: per channel within 1.5e-3 of max(|oracle|, 1e-3)
     rm = clamped_rmse(ex[..., :3] / P, want[..., :3] / P)
     off = int((np.abs(np.clip(ex[..., :3] / P, 0, 1) - np.clip(want[..., :3] / P, 0, 1)).max(-1) > 1e-3).sum())
     record({"key": "whole frame: " + name, "px": int(same.size), "strict_px_bit_identical_to_oracle": int(same.sum()), "nan_px": int(nan_w.sum()),
-            "exact_vs_oracle_rmse": rm, "exact_px_off_by_more_than_1e-3": off, "oracle_seconds": round(t_oracle, 1)})
+            "exact_vs_oracle_rmse": rm, "exact_vs_oracle_rmse_linear": tol["rmse_linear"], "exact_vs_oracle_max_rel": tol["max_rel"],
+            "exact_px_off_by_more_than_1e-3": off, "oracle_seconds": round(t_oracle, 1)})
     print("%s: STRICT %d / %d px bit-identical, %d NaN px on both sides; EXACT clamped RMSE %.3g, %d px off by > 1e-3; oracle %.0f s" % (
         name, int(same.sum()), same.size, int(nan_w.sum()), rm, off, t_oracle))
     assert rm < exact_rmse_bound and off == 0, (rm, off)

@@ -101,8 +101,7 @@ def test_three_argument_constructor_takes_the_whole_node(tmp_path, scenes):
     # refresh renders as many passes as fit a 30 Hz frame, so it may overshoot by part of a batch, as the reference's loop does)
     assert stats["gpus"] == torch.cuda.device_count() and 3 <= stats["passes"] <= 3 + 16
     acc = np.fromfile(raw, np.float32).reshape(90, 160, 4)
-    # (launch by launch as the scheduler rendered it: FAST and EXACT add the passes of a launch of 8, 16, 32 ... to the pixel's total
-    # in four groups -- tests/test_hip_tail_parts.py -- so the launches are part of what is compared)
+    # (rendered here launch by launch as the scheduler rendered it; since round 6 the cut no longer matters -- tests/test_hip_pass_cuts.py)
     with HipRenderer(sc, 160, 90, exact=True) as r:  # the form's numerics: EXACT (the reference's decisions on every path)
         for b in stats["batch_passes"]:
             r.render(b)

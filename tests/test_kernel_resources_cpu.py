@@ -144,9 +144,12 @@ def test_exact_kernels_keep_their_register_budgets():
 # adds more than ~3 % has to raise its budget here, knowingly. Measured at the time of writing: 1396, 1360, 2227, 2471, 2766, 3003
 # (the STRICT / EXACT kernels carry two sphere loops and two plane loops since round 5 -- the ones for scenes of (centre, radius) spheres
 # and rigid planes, +7 % / +6.5 %, and the general ones: ~170-250 instructions more in the text, fewer executed).
+# Round 6: 1456, 1420, 2278, 2520, 2768, 3004 -- the FAST / EXACT kernels' prologue forms a parted workgroup's compact side-buffer slot (one
+# integer division) and reads a group carried over from the launch before, their epilogue writes it (+60 instructions outside the loop;
+# the loop's blocks count 168 / 353 / 244 / 286 as before, tools/isa_blocks.sh).
 VALU_BUDGET = {
-    ("fast", "kajo_render_fast"): 1440,
-    ("fast", "kajo_render_fast_lights"): 1400,
+    ("fast", "kajo_render_fast"): 1500,
+    ("fast", "kajo_render_fast_lights"): 1465,
     ("exact", "kajo_render_exact"): 2290,
     ("exact", "kajo_render_exact_lights"): 2540,
     ("strict", "kajo_render_strict"): 2850,

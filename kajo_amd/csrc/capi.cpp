@@ -970,6 +970,7 @@ int kajo_hip_reset(kajo_hip_t h)
         HIP_TRY(hipMemsetAsync(h->counters, 0, 32 * sizeof(unsigned long long), h->stream));
     HIP_TRY(hipStreamSynchronize(h->stream));
     h->passesDone = 0;
+    h->carryValid = false;
     h->frameValid = false;
     h->kernelMs = 0.0;
     h->launches = 0;
@@ -984,6 +985,7 @@ int kajo_hip_set_pass_count(kajo_hip_t h, int passesDone)
     if (rc)
         return rc;
     h->passesDone = passesDone;
+    h->carryValid = false; // (a group in progress is not known apart from the buffer the caller declares: include/kajo_hip.h)
     h->frameValid = false;
     return KAJO_OK;
 }

@@ -79,6 +79,20 @@ KDEV F3 operator*(F3 a, F3 b) { return f3(a.x * b.x, a.y * b.y, a.z * b.z); }
 KDEV float dot(F3 a, F3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 KDEV F3 cross(F3 a, F3 b) { return f3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y); }
 KDEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
+// Sums of products that only SCALE what a path carries (its radiance, its throughput, a pdf toward a given direction): the EXACT build --
+// compiled -ffp-contract=off for the sake of everything that decides -- forms them with fused multiply-adds, spelled out so that every
+// kernel instance forms the same bits (a contraction left to the compiler is per instance). STRICT proper keeps the oracle's separate
+// roundings, FAST the expressions its compiler contracts as before.
+#ifndef KAJO_EXACT_FMA
+#define KAJO_EXACT_FMA 1
+#endif
+#if defined(KAJO_EXACT) && KAJO_EXACT && KAJO_EXACT_FMA
+KDEV float rdot(F3 a, F3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+KDEV F3 rmadd(F3 a, F3 b, F3 c) { return f3(__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y), __builtin_fmaf(a.z, b.z, c.z)); } // c + a * b
+#else
+KDEV float rdot(F3 a, F3 b) { return dot(a, b); }
+KDEV F3 rmadd(F3 a, F3 b, F3 c) { return c + a * b; }
+#endif
 
 // ---- numerics policy ------------------------------------------------------------------
 #if KAJO_STRICT
@@ -931,7 +945,7 @@ KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
 #endif
     }
     if (kind == 1) { // BSDF.cpp:62-67
-        float cosA = kmax0(dot(R, dir));
+        float cosA = kmax0(rdot(R, dir));
 #if KAJO_RSTRICT
         float s = (float)((double)(exponent + 1) / (2 * kPi));
 #else
@@ -939,7 +953,7 @@ KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
 #endif
         return (s * color) * kpowPhong(cosA, exponent);
     }
-    float cosA = kmax0(dot(dir, N)); // BSDF.cpp:87-91
+    float cosA = kmax0(rdot(dir, N)); // BSDF.cpp:87-91
 #if KAJO_RSTRICT
     return f3(kdiv(color.x, cosA), kdiv(color.y, cosA), kdiv(color.z, cosA));
 #else
@@ -950,7 +964,7 @@ KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
 KDEV float bsdfProbability(int kind, float exponent, F3 R, F3 N, F3 dir)
 {
     if (kind == 0) { // BSDF.cpp:35-39
-        float cosT = dot(dir, N);
+        float cosT = rdot(dir, N);
 #if KAJO_RSTRICT
         return (float)(kInvPi * (double)cosT);
 #else
@@ -958,7 +972,7 @@ KDEV float bsdfProbability(int kind, float exponent, F3 R, F3 N, F3 dir)
 #endif
     }
     if (kind == 1) { // BSDF.cpp:69-74
-        float cosA = kmax0(dot(R, dir));
+        float cosA = kmax0(rdot(R, dir));
 #if KAJO_RSTRICT
         return (float)((double)(exponent + 1) / (2 * kPi) * (double)kpowPhong(cosA, exponent));
 #else
@@ -973,7 +987,7 @@ KDEV float bsdfProbability(int kind, float exponent, F3 R, F3 N, F3 dir)
 KDEV F3 bsdfEvaluateWithPdf(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir, float& pdf)
 {
     if (kind == 1) { // BSDF.cpp:62-74
-        const float pw = kpowPhong(kmax0(dot(R, dir)), exponent);
+        const float pw = kpowPhong(kmax0(rdot(R, dir)), exponent);
 #if KAJO_RSTRICT
         pdf = (float)((double)(exponent + 1) / (2 * kPi) * (double)pw);
         const float s = (float)((double)(exponent + 1) / (2 * kPi));
@@ -1121,7 +1135,7 @@ KDEV float solidAngle(F3 centre, float radius, F3 P)
 KDEV float lightPdf(const DSphereCold& lc, F3 P)
 {
     F3 v = f3(lc.cx - P.x, lc.cy - P.y, lc.cz - P.z);
-    float d2 = dot(v, v);
+    float d2 = rdot(v, v);
     float r2 = lc.radius * lc.radius;
     float x2 = r2 * rrcp(d2);
     float p = (1.0f + __builtin_amdgcn_sqrtf(kmax0(1.0f - x2))) * d2 * lc.invTwoPiR2;
@@ -1185,6 +1199,9 @@ enum : int
 #endif
 #ifndef KAJO_LISTS_TILE_RMW
 #define KAJO_LISTS_TILE_RMW 0
+#endif
+#ifndef KAJO_STASH
+#define KAJO_STASH 0 // 1: the camera-ray stash experiment of round 6 (renderBody STASH; capi.cpp reserves its LDS under the same macro)
 #endif
 #ifndef KAJO_LISTS_BALANCED
 #define KAJO_LISTS_BALANCED 1 // 0: the light loop of rounds 4 (one vertex per lane), for A/B runs
@@ -1555,10 +1572,47 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #endif
     uint32_t trips = 0;
     int heldTrips = 0; // (wave-uniform) consecutive trips in which some lane wanted the light / BSDF blocks and they did not run
+    // STASH (an experiment of round 6, -DKAJO_STASH=1; measured in profiles/r06_notes.txt, not in the product): the camera-ray block -- a
+    // fifth of a trip's instructions, run in 96 % of the trips with half of the lanes -- treated as an occupancy problem. Whenever the block
+    // runs, every lane that is in the middle of a path and has no ray in store forms the camera ray of its NEXT path too (stream key, jitter
+    // draw, direction: the same arithmetic on the same operands) and parks it in seven LDS words of its own; a lane that starts a path
+    // takes the parked ray if it has one, and the block runs only in trips in which some lane starts a path without one.
+    constexpr bool STASH = KAJO_STASH && !KAT && !SPLIT && COLD_LDS && !LISTS;
+    float* const stashWords = reinterpret_cast<float*>(mailbox + 64 * stealWindow + (PARTS ? 64 : 0)) + lane; // [7][64] words, word k of the lane at k * 64
+    int stashState = 0; // 0: nothing parked; 1: the next sample of the pass being rendered; 2: the first sample of the lane's next own pass
     for (;;) {
         trips++;
         KAJO_STAMP(4); // tail of the previous trip (path bookkeeping, loop back-edge)
         // ---- MODE_NEW: camera ray of the next sample (Renderer.cpp:51-64) ---------------------
+        if (STASH && mode == MODE_NEW && stashState != 0) {
+            if (stashState == 2) { // the parked ray opens the lane's next pass: the one it has just finished is complete (Renderer.cpp:70-71)
+#if KAJO_RSTRICT
+                const F3 term = f3(kdiv(radiance.x, args.S), kdiv(radiance.y, args.S), kdiv(radiance.z, args.S));
+#else
+                const F3 term = radiance * invS;
+#endif
+                total = total + term;
+                ownPass++;
+                if (PARTS && ((ownPass - 1) & kGroupMask) == 0) {
+                    const DFloat4 a = *accWord;
+                    *accWord = DFloat4{a.x + total.x, a.y + total.y, a.z + total.z, a.w};
+                    total = f3(0.0f, 0.0f, 0.0f);
+                }
+                radiance = f3(0.0f, 0.0f, 0.0f);
+            }
+            rng.lo = (uint64_t)__builtin_bit_cast(uint32_t, stashWords[0]) | ((uint64_t)__builtin_bit_cast(uint32_t, stashWords[64]) << 32);
+            rng.hi = (uint64_t)__builtin_bit_cast(uint32_t, stashWords[128]) | ((uint64_t)__builtin_bit_cast(uint32_t, stashWords[192]) << 32);
+            d = f3(stashWords[256], stashWords[320], stashWords[384]);
+            const DFloat4 c3 = lds.camera[3];
+            O = f3(c3.x, c3.y, c3.z);
+            L = f3(0.0f, 0.0f, 0.0f);
+            T = f3(1.0f, 1.0f, 1.0f);
+            depth = 0;
+            collectEmission = true;
+            pendBsdf = false;
+            stashState = 0;
+            mode = MODE_EXTEND;
+        }
         KAJO_PROF(0, mode == MODE_NEW);
         if (KAT && mode == MODE_NEW) {
             if (katStarted) {
@@ -1639,7 +1693,29 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
                 idleMask &= idleMask - 1; // next idle lane
             }
-            if (mode == MODE_NEW && (stolenFrom >= 0 || ownPass < myEnd)) {
+        }
+        // (STASH: in a trip in which the block runs -- some lane starts a path empty-handed -- the lanes in the middle of a path of their own
+        // pixel park the ray of their next one: the next sample of the pass, or the first of the next own pass, whose number `pass` then
+        // takes at once -- a path of one's own pixel does not read it again)
+        bool parks = false;
+        {
+            const bool starts = !KAT && mode == MODE_NEW && (stolenFrom >= 0 || ownPass < myEnd);
+            if (STASH) {
+                const bool blockRuns = __ballot(mode == MODE_NEW) != 0ull; // (lanes that retire this trip count: their wave is near its end)
+                if (blockRuns && (mode == MODE_EXTEND || mode == MODE_SHADOW || mode == MODE_HOLD) && stashState == 0 && stolenFrom < 0) {
+                    if (!(sampleY == endY && sampleX == endX)) {
+                        parks = true;
+                        stashState = 1;
+                    } else if (ownPass + 1 < myEnd) {
+                        parks = true;
+                        stashState = 2;
+                        pass = ownPass + 1;
+                        sampleX = 0;
+                        sampleY = 0;
+                    }
+                }
+            }
+            if (starts || parks) {
                 // The pixel whose pass the lane is rendering: its own, or the one of the lane it took the pass over from (same
                 // 8x8 block). Its stream key word and x * pixelWidth, (H - y) * pixelHeight of Renderer.cpp:56-57 are formed here
                 // rather than carried in six registers through the whole loop.
@@ -1653,29 +1729,42 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 KAJO_QUARTER_ROUND(a, b, c, dd);
                 KAJO_QUARTER_ROUND(a, b, c, dd);
                 KAJO_QUARTER_ROUND(a, b, c, dd);
-                rng.lo = (uint64_t)a | ((uint64_t)b << 32);
-                rng.hi = (uint64_t)c | ((uint64_t)dd << 32);
-                rngStep(rng);
-                float offX = unitBits((uint32_t)rng.lo);
-                float offY = unitBits((uint32_t)(rng.lo >> 32));
+                Rng fresh;
+                fresh.lo = (uint64_t)a | ((uint64_t)b << 32);
+                fresh.hi = (uint64_t)c | ((uint64_t)dd << 32);
+                rngStep(fresh);
+                float offX = unitBits((uint32_t)fresh.lo);
+                float offY = unitBits((uint32_t)(fresh.lo >> 32));
                 float sx = curPixX + sampleX * c5.z + offX * c5.z;
                 float sy = curPixY + sampleY * c5.w + offY * c5.w;
                 const DFloat4 c0 = lds.camera[0], c1 = lds.camera[1], c2 = lds.camera[2], c3 = lds.camera[3];
                 const F3 camOrigin = f3(c3.x, c3.y, c3.z);
                 F3 dir = f3(c0.x, c0.y, c0.z) + f3(c1.x, c1.y, c1.z) * sx + f3(c2.x, c2.y, c2.z) * sy - camOrigin;
-                d = normalize(dir);
-                O = camOrigin;
-                L = f3(0.0f, 0.0f, 0.0f);
-                T = f3(1.0f, 1.0f, 1.0f);
-                depth = 0;
-                collectEmission = true;
-                pendBsdf = false;
+                const F3 nd = normalize(dir);
                 sampleX++;
                 if (sampleX == n) {
                     sampleX = 0;
                     sampleY++;
                 }
-                mode = MODE_EXTEND;
+                if (STASH && parks) {
+                    stashWords[0] = __builtin_bit_cast(float, (uint32_t)fresh.lo);
+                    stashWords[64] = __builtin_bit_cast(float, (uint32_t)(fresh.lo >> 32));
+                    stashWords[128] = __builtin_bit_cast(float, (uint32_t)fresh.hi);
+                    stashWords[192] = __builtin_bit_cast(float, (uint32_t)(fresh.hi >> 32));
+                    stashWords[256] = nd.x;
+                    stashWords[320] = nd.y;
+                    stashWords[384] = nd.z;
+                } else {
+                    rng = fresh;
+                    d = nd;
+                    O = camOrigin;
+                    L = f3(0.0f, 0.0f, 0.0f);
+                    T = f3(1.0f, 1.0f, 1.0f);
+                    depth = 0;
+                    collectEmission = true;
+                    pendBsdf = false;
+                    mode = MODE_EXTEND;
+                }
             }
         }
         int aliveCount;
@@ -1737,7 +1826,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             }
             if (hit.id == 0) { // Shader.cpp:116-117
                 const DFloat4 bg = lds.camera[4];
-                L = L + T * f3(bg.x, bg.y, bg.z);
+                L = rmadd(T, f3(bg.x, bg.y, bg.z), L);
                 pathDone = true;
             } else {
                 ctrVertices += 1; // (unconditionally: an inline constant, where `counting` as an addend would be one more live register)
@@ -1754,7 +1843,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     float sEnd = m0.w;
                     if (cont)
                         sEnd = mq[4].w;
-                    L = L + T * (sEnd * vE);
+                    L = rmadd(T, sEnd * vE, L);
                     pathDone = true;
                 } else {
                     float pt;
@@ -1764,15 +1853,15 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     if (transparent) { // Shader.cpp:137-151; the BSDF colour is the SPECULAR colour
                         const DFloat4 m2 = mq[2], m4 = mq[4];
                         F3 nd = transmissionDirection(view, vN, m2.w);
-                        float cosA = __builtin_fabsf(dot(nd, vN));
+                        float cosA = __builtin_fabsf(rdot(nd, vN));
                         F3 spec = f3(m2.x, m2.y, m2.z);
 #if KAJO_RSTRICT
                         F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
 #else
                         F3 f = spec * rrcp(cosA);
 #endif
-                        F3 w = (m4.z * f) * __builtin_fabsf(dot(vN, nd)); // sTransparent = 1/pc * 1/pt, Shader.cpp:146-147
-                        L = L + T * (w * vE);
+                        F3 w = (m4.z * f) * __builtin_fabsf(rdot(vN, nd)); // sTransparent = 1/pc * 1/pt, Shader.cpp:146-147
+                        L = rmadd(T, w * vE, L);
                         T = T * w;
                         O = vP + nd * kEps;
                         d = nd;
@@ -1817,7 +1906,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #else
                 // ... and waits in the vertex's dead registers: direction in vN, path-weight factor in vR (see the BSDF sampling block)
                 const DFloat4 v4 = reinterpret_cast<const DFloat4*>(lds.material + (vId - 1))[4];
-                L = L + T * ((vKind == 0 ? v4.x : v4.y) * vE);
+                L = rmadd(T, (vKind == 0 ? v4.x : v4.y) * vE, L);
                 T = T * vR;
                 O = vP + vN * kEps;
                 d = vN;
@@ -2326,7 +2415,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
 #else
                 const F3 dB = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
-                const F3 w = vSl * ((rrcp(p) * fd) * kmax0(dot(vN, dB)));
+                const F3 w = vSl * ((rrcp(p) * fd) * kmax0(rdot(vN, dB)));
                 pendP = p;
                 pendBsdf = true;
                 depth++;
@@ -2334,7 +2423,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     vN = dB;
                     vR = w;
                 } else {
-                    L = L + T * (vSl * vE);
+                    L = rmadd(T, vSl * vE, L);
                     // The next segment's state is written unconditionally: a path that ends here (p == 0) re-initialises
                     // all of it when its lane starts the next camera path, and unconditional writes need no copies.
                     T = T * w;

@@ -1200,6 +1200,9 @@ enum : int
 #ifndef KAJO_LISTS_TILE_RMW
 #define KAJO_LISTS_TILE_RMW 0
 #endif
+#ifndef KAJO_ANY_LANE_GIVES
+#define KAJO_ANY_LANE_GIVES 1 // 0: only lanes that are themselves between two paths in this trip can give a pass away (rounds 2-5)
+#endif
 #ifndef KAJO_STASH
 #define KAJO_STASH 0 // 1: the camera-ray stash experiment of round 6 (renderBody STASH; capi.cpp reserves its LDS under the same macro)
 #endif
@@ -1631,6 +1634,34 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 mode = MODE_EXTEND;
             }
         }
+        constexpr bool ANY_GIVES = KAJO_ANY_LANE_GIVES && !SPLIT; // (the SPLIT kernels' waves are short: the wider ballot only costs them registers)
+        // Out of own passes: take one over, or retire when nobody has one to give. ANY lane of the wave that still has a pass it has not
+        // begun can give it -- also one in the middle of a path (round 6, STRICT / EXACT builds; until then, and in the FAST build and the
+        // SPLIT kernels still, only lanes that are between two paths in the same trip are asked, and a lane retires for want of a giver
+        // while others still have passes to spare).
+        const auto takeOverPasses = [&]() {
+            unsigned long long idleMask = __ballot(mode == MODE_NEW && stolenFrom < 0 && ownPass >= myEnd);
+            while (idleMask) { // wave-uniform; only in the last stretch of the wave's life
+                const int give = myEnd - 1; // the pass this lane could give away (a parked camera ray of the next pass has begun it)
+                const unsigned long long giverMask = __ballot((ANY_GIVES || mode == MODE_NEW) && mode != MODE_DONE && stolenFrom < 0 &&
+                                                              give > ownPass + (STASH && stashState == 2 ? 1 : 0) && give >= stealBase);
+                if (giverMask == 0ull) {
+                    if (mode == MODE_NEW && stolenFrom < 0 && ownPass >= myEnd)
+                        mode = MODE_DONE;
+                    break;
+                }
+                // lowest idle lane takes the last pass of the lowest giver
+                const int thief = __builtin_ctzll(idleMask), giver = __builtin_ctzll(giverMask);
+                const int takenPass = __builtin_amdgcn_readlane(myEnd, giver) - 1;
+                if (lane == giver)
+                    myEnd = takenPass;
+                if (lane == thief) {
+                    stolenFrom = giver;
+                    pass = takenPass;
+                }
+                idleMask &= idleMask - 1; // next idle lane
+            }
+        };
         if (!KAT && mode == MODE_NEW) {
             if (sampleY == endY && sampleX == endX) { // pass complete: Renderer.cpp:70-71
 #if KAJO_RSTRICT
@@ -1672,28 +1703,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 sampleY = sampleBegin / n;
                 pass = ownPass;
             }
-            // out of own passes: take one over, or retire when nobody has one to give
-            unsigned long long idleMask = __ballot(stolenFrom < 0 && ownPass >= myEnd);
-            while (idleMask) { // wave-uniform; only in the last stretch of the wave's life
-                const int give = myEnd - 1; // the pass this lane could give away
-                const unsigned long long giverMask = __ballot(mode != MODE_DONE && stolenFrom < 0 && give > ownPass && give >= stealBase);
-                if (giverMask == 0ull) {
-                    if (stolenFrom < 0 && ownPass >= myEnd)
-                        mode = MODE_DONE;
-                    break;
-                }
-                // lowest idle lane takes the last pass of the lowest giver
-                const int thief = __builtin_ctzll(idleMask), giver = __builtin_ctzll(giverMask);
-                const int takenPass = __builtin_amdgcn_readlane(myEnd, giver) - 1;
-                if (lane == giver)
-                    myEnd = takenPass;
-                if (lane == thief) {
-                    stolenFrom = giver;
-                    pass = takenPass;
-                }
-                idleMask &= idleMask - 1; // next idle lane
-            }
+            if (!ANY_GIVES)
+                takeOverPasses();
         }
+        if (!KAT && ANY_GIVES)
+            takeOverPasses();
         // (STASH: in a trip in which the block runs -- some lane starts a path empty-handed -- the lanes in the middle of a path of their own
         // pixel park the ray of their next one: the next sample of the pass, or the first of the next own pass, whose number `pass` then
         // takes at once -- a path of one's own pixel does not read it again)

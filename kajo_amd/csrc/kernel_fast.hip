@@ -4,6 +4,9 @@
 #ifndef KAJO_WAVES_PER_SIMD
 #define KAJO_WAVES_PER_SIMD 5 // the FAST loop fits 96 VGPRs without spills (tools/vgpr_check.sh)
 #endif
+#ifndef KAJO_ANY_LANE_GIVES
+#define KAJO_ANY_LANE_GIVES 0 // (integrator.inc.hip: measured -0.3 % on configs[1], -2 % on configs[4] in this build, +0.4 ... +0.9 % in the other two: profiles/r06_notes.txt)
+#endif
 #define KAJO_KERNEL_NAME kajo_render_fast
 #ifndef KAJO_PRESAMPLE
 #define KAJO_PRESAMPLE 1

@@ -82,7 +82,10 @@ KDEV F3 ld3(const float* p) { return f3(p[0], p[1], p[2]); }
 // Sums of products that only SCALE what a path carries (its radiance, its throughput, a pdf toward a given direction): the EXACT build --
 // compiled -ffp-contract=off for the sake of everything that decides -- forms them with fused multiply-adds, spelled out so that every
 // kernel instance forms the same bits (a contraction left to the compiler is per instance). STRICT proper keeps the oracle's separate
-// roundings, FAST the expressions its compiler contracts as before.
+// roundings, FAST the expressions its compiler contracts as before. NOT for a cosine that something is divided by: where the oracle's
+// separately rounded dot product is exactly zero the quotient is infinite and inf * 0 a not-a-number pixel (the reference has them:
+// grazing glass and mirror hits), which a fused sum -- almost never exactly zero -- would turn into a finite one (caustics scene: 19
+// such pixels against the oracle's 29, tests/test_hip_whole_frames.py).
 #ifndef KAJO_EXACT_FMA
 #define KAJO_EXACT_FMA 1
 #endif
@@ -953,7 +956,7 @@ KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
 #endif
         return (s * color) * kpowPhong(cosA, exponent);
     }
-    float cosA = kmax0(rdot(dir, N)); // BSDF.cpp:87-91
+    float cosA = kmax0(dot(dir, N)); // BSDF.cpp:87-91 (an exact zero makes the value infinite, and inf * 0 a NaN pixel the oracle has too: not rdot)
 #if KAJO_RSTRICT
     return f3(kdiv(color.x, cosA), kdiv(color.y, cosA), kdiv(color.z, cosA));
 #else
@@ -964,7 +967,7 @@ KDEV F3 bsdfEvaluate(int kind, F3 color, float exponent, F3 R, F3 N, F3 dir)
 KDEV float bsdfProbability(int kind, float exponent, F3 R, F3 N, F3 dir)
 {
     if (kind == 0) { // BSDF.cpp:35-39
-        float cosT = rdot(dir, N);
+        float cosT = dot(dir, N);
 #if KAJO_RSTRICT
         return (float)(kInvPi * (double)cosT);
 #else
@@ -1867,14 +1870,14 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     if (transparent) { // Shader.cpp:137-151; the BSDF colour is the SPECULAR colour
                         const DFloat4 m2 = mq[2], m4 = mq[4];
                         F3 nd = transmissionDirection(view, vN, m2.w);
-                        float cosA = __builtin_fabsf(rdot(nd, vN));
+                        float cosA = __builtin_fabsf(dot(nd, vN)); // (divided by: its exact zeros are the oracle's NaN pixels)
                         F3 spec = f3(m2.x, m2.y, m2.z);
 #if KAJO_RSTRICT
                         F3 f = f3(kdiv(spec.x, cosA), kdiv(spec.y, cosA), kdiv(spec.z, cosA)); // BSDF.cpp:126-130
 #else
                         F3 f = spec * rrcp(cosA);
 #endif
-                        F3 w = (m4.z * f) * __builtin_fabsf(rdot(vN, nd)); // sTransparent = 1/pc * 1/pt, Shader.cpp:146-147
+                        F3 w = (m4.z * f) * __builtin_fabsf(dot(vN, nd)); // sTransparent = 1/pc * 1/pt, Shader.cpp:146-147
                         L = rmadd(T, w * vE, L);
                         T = T * w;
                         O = vP + nd * kEps;
@@ -2429,7 +2432,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 }
 #else
                 const F3 dB = bsdfGenerate(vKind, vColor, vExp, vR, vN, tg, bn, rng, p, fd);
-                const F3 w = vSl * ((rrcp(p) * fd) * kmax0(rdot(vN, dB)));
+                const F3 w = vSl * ((rrcp(p) * fd) * kmax0(dot(vN, dB)));
                 pendP = p;
                 pendBsdf = true;
                 depth++;

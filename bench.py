@@ -261,6 +261,37 @@ def scheduler_run_leg(scene, W, H, passes, numerics, frames=8):
             "command": "kajo_render -w %d -h %d -r hip --passes %d --batch %d --gpus 1 --json --scene-pod <spheres.json fixture> --%s" % (W, H, passes * (frames + 2), passes, numerics)}
 
 
+STAGE_TAG = "KAJO_BENCH_STAGE"
+
+
+def note_stage(rank, stage):
+    """Every rank says on stderr where it is: what the parent (or a reader of the driver's log) sees last is where a run stopped."""
+    STATE["stage"] = stage
+    sys.stderr.write("%s rank=%d stage=%s\n" % (STAGE_TAG, rank, stage))
+    sys.stderr.flush()
+
+
+STATE = {"stage": "start", "printed": False}
+
+
+def stage_from_stderr(lines):
+    """-> {rank: last stage it reported}"""
+    last = {}
+    for l in lines:
+        if l.startswith(STAGE_TAG):
+            f = dict(kv.split("=", 1) for kv in l.split()[1:] if "=" in kv)
+            last[int(f.get("rank", -1))] = f.get("stage", "?")
+    return last
+
+
+def error_line(n_gpus, args, stage, error, stderr_tail=None):
+    """The ONE JSON line of a run that failed: the contract's keys with value null, and where / why it stopped."""
+    return {"metric": "Msamples/s", "value": None, "unit": "Msamples/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": None, "higher_is_better": True, "scaling": "strong" if n_gpus > 1 else None, "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic", "error": error, "stage": stage, "stderr_tail": stderr_tail,
+            "config": {"backend": args.backend if n_gpus > 1 else None, "gather_direct": bool(getattr(args, "gather_direct", False))}}
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -287,9 +318,14 @@ def main():
     ap.add_argument("--separate-compose", action="store_true",
                     help="N > 1: rank 0 composes the whole float frame and resolves that (two passes over the data, rounds 1-3) instead "
                          "of resolving straight from the gathered tile buffers")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo: rehearsal of the N > 1 control flow on fewer GPUs than ranks (gather staged through "
-                         "host memory, every rank on GPU LOCAL_RANK %% device_count); the graded runs use nccl = RCCL")
+    ap.add_argument("--backend", default="nccl",
+                    help="nccl (= RCCL; the graded runs) or gloo: rehearsal of the N > 1 control flow on fewer GPUs than ranks (gather staged "
+                         "through host memory, every rank on GPU LOCAL_RANK %% device_count). Any other name fails in init_process_group "
+                         "(tests/test_multi_rank_cpu.py uses that to see the error line)")
+    ap.add_argument("--gather-direct", action="store_true",
+                    help="N > 1, nccl: send straight from the library's own tile buffer instead of a torch-allocated copy of it (the copy is "
+                         "there because memory the library allocated is foreign to the process group's allocator: this switch lets a run on "
+                         "real hardware tell whether it is needed)")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")
@@ -298,12 +334,63 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+        # The ranks' stdout is passed on (rank 0 prints the line); their stderr is shown AND kept, so that a failed run -- the first
+        # contact with N > 1 hardware must be diagnosable -- still ends in ONE parseable JSON line: which stage, which rank, the
+        # tail of what the ranks said.
+        p = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        import threading
+        err_lines = []
+
+        def pump():
+            for line in p.stderr:
+                sys.stderr.write(line)
+                err_lines.append(line)
+
+        t = threading.Thread(target=pump, daemon=True)
+        t.start()
+        out_text = p.stdout.read()
+        rc = p.wait()
+        t.join(timeout=10)
+        sys.stdout.write(out_text)
+        has_line = any(l.startswith("{") and '"metric"' in l for l in out_text.splitlines())
+        if rc != 0 or not has_line:
+            if not has_line:  # (a rank-0 failure prints its own error line: not a second one)
+                said = [l.strip() for l in err_lines if l.startswith("KAJO_BENCH_ERROR")]
+                what = ("the ranks exited with code %d" % rc if rc else "the ranks printed no result line") + ("; " + said[0] if said else "")
+                print(json.dumps(error_line(args.gpus, args, stage_from_stderr(err_lines), what, "".join(err_lines[-40:]))), flush=True)
+            raise SystemExit(rc or 1)
+        raise SystemExit(0)
     world = int(env_world or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if world > 1:
+        # A rank that fails takes the others down with it (torch.distributed.run sends them SIGTERM): rank 0 then still prints the line.
+        import signal
+
+        def terminated(signum, frame):
+            if rank == 0 and not STATE["printed"]:
+                STATE["printed"] = True
+                print(json.dumps(error_line(world, args, {0: STATE["stage"]}, "rank 0 was terminated (signal %d) at stage '%s': another rank "
+                                            "failed or the launcher gave up; the ranks' stderr has their stages" % (signum, STATE["stage"]))), flush=True)
+            os._exit(1)
+
+        signal.signal(signal.SIGTERM, terminated)
+    try:
+        run_ranks(args, world, rank, local_rank)
+    except BaseException as e:  # (SystemExit with a message included: "needs a GPU")
+        if isinstance(e, SystemExit) and e.code in (0, None):
+            raise
+        if world > 1:
+            sys.stderr.write("KAJO_BENCH_ERROR rank=%d stage=%s: %s: %s\n" % (rank, STATE["stage"], type(e).__name__, e))
+            if rank == 0 and not STATE["printed"]:
+                STATE["printed"] = True
+                print(json.dumps(error_line(world, args, {0: STATE["stage"]}, "%s: %s" % (type(e).__name__, e))), flush=True)
+        raise
+
+
+def run_ranks(args, world, rank, local_rank):
     numerics = "fast" if args.fast else ("strict" if args.strict else "exact")
     sched_leg = None
     if world == 1 and not args.no_cpu_baseline and args.workload in ("auto", "c2") and torch.cuda.device_count() > 0:
@@ -311,19 +398,22 @@ def main():
         from kajo_amd.scene import Scene as _Scene
         _z = np.load(os.path.join(ROOT, "tests", "golden", "scenes.npz"))
         sched_leg = scheduler_run_leg(_Scene.from_npz(_z, "spheres_a169/", "spheres.json 16:9"), *WORKLOADS["c2"][:3], numerics)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: the backend has no CPU path")
-    if args.backend == "gloo":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        if args.backend != "nccl":  # (host-side backends need no device: the group comes first, so that its failures are not masked)
+            note_stage(rank, "init_process_group(%s)" % args.backend)
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    note_stage(rank, "device")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the backend has no CPU path")
+    if args.backend != "nccl":
+        local_rank %= torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+    if world > 1 and args.backend == "nccl":
+        note_stage(rank, "init_process_group(nccl)")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from kajo_amd import capi
     from kajo_amd.renderer import HipRenderer
@@ -367,8 +457,11 @@ def main():
         if world > 1:
             ev[0].record()
             if args.backend == "nccl":
-                send.copy_(mine)
-                gather_to_root(dist, send, gathered, rank, world)
+                if args.gather_direct:
+                    gather_to_root(dist, mine, gathered, rank, world)
+                else:
+                    send.copy_(mine)
+                    gather_to_root(dist, send, gathered, rank, world)
             else:  # rehearsal: gloo moves host tensors
                 host = torch.empty(world * mine.numel()) if rank == 0 else None
                 gather_to_root(dist, mine.cpu(), host, rank, world)
@@ -393,9 +486,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    note_stage(rank, "first step (render + gather + resolve)" if world > 1 else "warmup")
+    for k in range(max(args.warmup, 1 if world > 1 else 0)):  # (N > 1: at least one untimed step, so that the first gather is a stage of its own)
         step()
+        if k == 0:
+            note_stage(rank, "warmup")
     fence()
+    note_stage(rank, "timed steps")
     c0 = r.counters()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -435,6 +532,7 @@ def main():
     # ---- N > 1: the composed frame against ONE GPU rendering the same frame alone, bit for bit (2 steps) ---------
     check = None
     if world > 1 and not args.no_check:
+        note_stage(rank, "bit-for-bit check against one GPU")
         r.reset()
         for _ in range(2):
             step()
@@ -461,6 +559,7 @@ def main():
                      "efficiency_vs_one_gpu_same_frame": value / solo_value / world}
         fence()
 
+    note_stage(rank, "report")
     out = None
     if rank == 0:
         kernel = "kajo_render_" + numerics
@@ -576,6 +675,9 @@ def main():
             out["north_star_mode"] = None
             out["headline_is_north_star_mode"] = False
     if rank == 0:
+        if world > 1:
+            out["config"]["gather_direct"] = bool(args.gather_direct)
+        STATE["printed"] = True
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -302,6 +302,9 @@ struct LdsScene
 // One sphere of Raytracer.cpp:21-72 up to (not including) processIntersection: returns false when the
 // reference returns early (discriminant < 0, or both roots behind the origin); otherwise th = the
 // object-space parameter the reference reports and ts = th * determinant.
+// ALLT: every sphere of the scene is known to be a (centre, radius) record (the kernels of scenes with visibility lists: stage.cpp builds
+// lists only for such scenes) -- the general record's code is not compiled in.
+template <bool ALLT = false>
 KDEV bool sphereCandidate(const DSceneView& sc, const LdsScene& lds, int i, F3 O, F3 d, float aT, float iaT, float& ts, float& th)
 {
     // a t^2 + 2 h t + c = 0 in object space (the reference's b = 2 h); ia = 1 / a
@@ -309,8 +312,8 @@ KDEV bool sphereCandidate(const DSceneView& sc, const LdsScene& lds, int i, F3 O
 #if !KAJO_STRICT
     float ia;
 #endif
-    const uint32_t off = sc.allTranslated ? (uint32_t)i : lds.sphereHotOffset[i];
-    if (!(off & KAJO_SPHERE_GENERAL)) {
+    const uint32_t off = (ALLT || sc.allTranslated) ? (uint32_t)i : lds.sphereHotOffset[i];
+    if (ALLT || !(off & KAJO_SPHERE_GENERAL)) {
         const DFloat4 s = lds.sphereHot[off];
         F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
         a = aT;
@@ -371,6 +374,7 @@ KDEV bool sphereCandidate(const DSceneView& sc, const LdsScene& lds, int i, F3 O
 // Large scenes: visit only the spheres registered in the grid cells the ray crosses, front to back.
 // Acceptance reproduces the brute-force walk: closest ts wins; among equal ts the later object wins
 // (Raytracer.cpp:115 rejects only ts > max), so a sphere ties over a plane and over a lower-index sphere.
+template <bool ALLT>
 KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* gridCellStart, const uint16_t* gridItems, F3 O, F3 d, float aT,
                      float iaT, float& tMax, int& best, float& bestT0)
 {
@@ -424,7 +428,7 @@ KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* 
         const uint32_t k0 = gridCellStart[cell];
         const uint32_t e = gridCellStart[cell + 1];
 #if !KAJO_STRICT
-        if (sc.allTranslated) {
+        if (ALLT || sc.allTranslated) {
             // (centre, radius) spheres with the bookkeeping of the brute-force walk: the smaller non-negative root is
             // the smaller bit pattern, "exists, not behind, closer" one unsigned compare (plus the tie rule)
             // Closest wins; among bit-identical distances the LATER object (Raytracer.cpp:115 rejects only t > max, objects in scene
@@ -456,7 +460,7 @@ KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* 
             KAJO_COUNT_TESTS(lds, 0);
             const int i = (int)gridItems[k];
             float ts, th;
-            const bool valid = sphereCandidate(sc, lds, i, O, d, aT, iaT, ts, th);
+            const bool valid = sphereCandidate<ALLT>(sc, lds, i, O, d, aT, iaT, ts, th);
             const int id = np + 1 + i;
             const bool ok = valid && !(ts < 0.0f) && (ts < tMax || (ts == tMax && id > best));
             tMax = ok ? ts : tMax;
@@ -482,33 +486,35 @@ KDEV void gridWalkIn(const DSceneView& sc, const LdsScene& lds, const uint32_t* 
 
 // GHOME: where the grid's cell lists live -- 1 in LDS, 2 in global memory (the STRICT large-scene kernel instances, which know: typed
 // loads, one walk; kernel_strict.hip), 0 decided at run time (the known-answer kernels; the FAST render kernels, which carry both typed walks)
-template <int GHOME>
+template <int GHOME, bool ALLT>
 KDEV void gridWalk(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, float aT, float iaT, float& tMax, int& best, float& bestT0)
 {
     if (GHOME == 1) {
-        gridWalkIn(sc, lds, lds.gridCellStartLds, lds.gridItemsLds, O, d, aT, iaT, tMax, best, bestT0);
+        gridWalkIn<ALLT>(sc, lds, lds.gridCellStartLds, lds.gridItemsLds, O, d, aT, iaT, tMax, best, bestT0);
         return;
     }
     if (GHOME == 2) {
-        gridWalkIn(sc, lds, sc.grid.cellStart, sc.grid.items, O, d, aT, iaT, tMax, best, bestT0);
+        gridWalkIn<ALLT>(sc, lds, sc.grid.cellStart, sc.grid.items, O, d, aT, iaT, tMax, best, bestT0);
         return;
     }
 #if KAJO_STRICT
     // (the known-answer kernels: one instance over a pointer of either home -- flat loads; a second instance costs 20 more spilled registers)
-    gridWalkIn(sc, lds, sc.grid.inLds ? lds.gridCellStartLds : sc.grid.cellStart, sc.grid.inLds ? lds.gridItemsLds : sc.grid.items, O, d, aT, iaT, tMax,
+    gridWalkIn<ALLT>(sc, lds, sc.grid.inLds ? lds.gridCellStartLds : sc.grid.cellStart, sc.grid.inLds ? lds.gridItemsLds : sc.grid.items, O, d, aT, iaT, tMax,
                best, bestT0);
 #else
     if (sc.grid.inLds) // (wave-uniform) LDS reads
-        gridWalkIn(sc, lds, lds.gridCellStartLds, lds.gridItemsLds, O, d, aT, iaT, tMax, best, bestT0);
+        gridWalkIn<ALLT>(sc, lds, lds.gridCellStartLds, lds.gridItemsLds, O, d, aT, iaT, tMax, best, bestT0);
     else // global loads
-        gridWalkIn(sc, lds, sc.grid.cellStart, sc.grid.items, O, d, aT, iaT, tMax, best, bestT0);
+        gridWalkIn<ALLT>(sc, lds, sc.grid.cellStart, sc.grid.items, O, d, aT, iaT, tMax, best, bestT0);
 #endif
 }
 
 // hasRay: the lane has a ray to trace. Lanes without one (holding a vertex, done) go through the motions of the every-object walk
 // -- it is the same instructions for the whole wave either way -- but must NOT set out on a grid walk with whatever their ray
 // registers hold: a wave walks as long as its longest lane.
-template <bool GRID, int GHOME = 0>
+// LISTS_SCENE: the scene is known to have visibility lists -- and so (stage.cpp buildShadowLists / buildGrid) a closed room, the grid, rigid
+// planes and nothing but (centre, radius) spheres: the kernel instances of such scenes carry one plane loop and the grid walk, nothing else.
+template <bool GRID, int GHOME = 0, bool LISTS_SCENE = false>
 KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRay = true)
 {
     float tMax = __builtin_inff(); // Ray.cpp:10-13; minDistance = 0
@@ -526,7 +532,7 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
     uint32_t kMax = 0x7f800000u; // +inf
     uint32_t idV = 1;
     asm volatile("" : "+v"(idV));
-    if (sc.planesRigid) {
+    if (LISTS_SCENE || sc.planesRigid) {
         // |det - 1| <= 2^-20 for every plane: t * det is t to within its own rounding, and the
         // second sign test repeats the first
         for (int i = 0; i < np; i++) {
@@ -546,7 +552,7 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
     } else
 #endif
 #if KAJO_STRICT
-    if (sc.planesRigid) {
+    if (LISTS_SCENE || sc.planesRigid) {
         // Every determinant within 2^-20 of 1 (all of the reference's data/ scenes: rotations and translations): t * det has the sign
         // of t -- a positive factor cannot make a product negative, and -0 stays -0, which `< 0` does not hold for either -- so
         // Raytracer.cpp:115's `t < ray.min` repeats :85-86's `t < 0` and is not asked again. The same t, the same t * det.
@@ -586,7 +592,7 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
 #else
     const float iaT = 0.0f;
 #endif
-    if (GRID && sc.grid.enabled) {
+    if (GRID && (LISTS_SCENE || sc.grid.enabled)) {
 #if KAJO_STRICT
         // A ray that is not a number (a light sample whose square root went negative, Light.cpp:43-46; the Phong frame of a
         // reflection along z, BSDF.cpp:52-54): in the reference's walk every comparison with NaN is false, so every object is
@@ -600,14 +606,14 @@ KDEV Hit trace(const DSceneView& sc, const LdsScene& lds, F3 O, F3 d, bool hasRa
         // an open floor; never in a closed room -- takes its wave to the every-sphere loop below, which needs no margin.
         // (reach2 = 3e38 -- the closed room of every scene in the reference's data/ -- skips the test: a scalar branch)
         bool anyFar = false;
-        if (sc.grid.reach2 < 1e38f) {
+        if (!LISTS_SCENE && sc.grid.reach2 < 1e38f) {
             const DFloat4 gc = lds.gridHeader[4];
             const float fx = O.x - gc.x, fy = O.y - gc.y, fz = O.z - gc.z;
             anyFar = __builtin_amdgcn_ballot_w64(hasRay && !(fx * fx + fy * fy + fz * fz <= gc.w)) != 0ull;
         }
         if (!anyFar) {
             if (hasRay)
-                gridWalk<GHOME>(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
+                gridWalk<GHOME, LISTS_SCENE>(sc, lds, O, d, aT, iaT, tMax, best, bestT0);
             return Hit{best, tMax, bestT0};
         }
     }
@@ -709,7 +715,7 @@ KDEV bool lightReachedHead(const DSceneView& sc, const LdsScene& lds, int lightK
         return si == sc.nSpheres - 1;
     }
     float tsL, thL;
-    if (!sphereCandidate(sc, lds, si, O, d, aT, 0.0f, tsL, thL) || tsL < 0.0f)
+    if (!sphereCandidate<true>(sc, lds, si, O, d, aT, 0.0f, tsL, thL) || tsL < 0.0f)
         return false;
     keyL = __builtin_bit_cast(uint32_t, tsL);
     // A plane that has the ray's origin AND the light's whole ball strictly on one side (by margins far above the rounding of
@@ -766,7 +772,7 @@ KDEV bool shadowItemBlocks(const DSceneView& sc, const LdsScene& lds, int i, int
 {
 #if KAJO_STRICT
     float ts, th;
-    const bool valid = sphereCandidate(sc, lds, i, O, d, aT, 0.0f, ts, th);
+    const bool valid = sphereCandidate<true>(sc, lds, i, O, d, aT, 0.0f, ts, th);
     const float tsL = __builtin_bit_cast(float, keyL);
     return valid && !(ts < 0.0f) && (ts < tsL || (ts == tsL && i > si));
 #else
@@ -904,6 +910,7 @@ KDEV void sphereFrame(F3 n, F3& tg, F3& bn) // Raytracer.cpp:55-65
     bn = cross(n, tg);
 }
 
+template <bool ALLT = false>
 KDEV F3 hitNormal(const DSceneView& sc, const LdsScene& lds, const Hit& h, F3 O, F3 d)
 {
     if (h.id <= sc.nPlanes) {
@@ -911,8 +918,8 @@ KDEV F3 hitNormal(const DSceneView& sc, const LdsScene& lds, const Hit& h, F3 O,
         return f3(n.x, n.y, n.z);
     }
     const int si = h.id - 1 - sc.nPlanes;
-    const uint32_t off = sc.allTranslated ? (uint32_t)si : lds.sphereHotOffset[si];
-    if (!(off & KAJO_SPHERE_GENERAL)) {
+    const uint32_t off = (ALLT || sc.allTranslated) ? (uint32_t)si : lds.sphereHotOffset[si];
+    if (ALLT || !(off & KAJO_SPHERE_GENERAL)) {
 #if KAJO_STRICT
         const DFloat4 s = lds.sphereHot[off];
         F3 o = f3(O.x + s.x, O.y + s.y, O.z + s.z);
@@ -1795,7 +1802,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 
         KAJO_STAMP(0); // camera-ray block
         // ---- one ray per lane through the whole scene ------------------------------------------
-        const Hit hit = trace<!COLD_LDS, GHOME>(sc, lds, O, d, mode == MODE_EXTEND || mode == MODE_SHADOW);
+        const Hit hit = trace<!COLD_LDS, GHOME, LISTS>(sc, lds, O, d, mode == MODE_EXTEND || mode == MODE_SHADOW);
         KAJO_STAMP(1); // traversal
         if (counting) {
             ctrTraversals += __builtin_popcountll(activeMask);
@@ -1849,7 +1856,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 ctrVertices += 1; // (unconditionally: an inline constant, where `counting` as an addend would be one more live register)
                 const F3 view = d;
                 vP = O + d * hit.t; // Raytracer.cpp:134-135
-                vN = hitNormal(sc, lds, hit, O, d);
+                vN = hitNormal<LISTS>(sc, lds, hit, O, d);
                 vId = hit.id;
                 vE = collectEmission ? f3(m1.x, m1.y, m1.z) : f3(0.0f, 0.0f, 0.0f); // Shader.cpp:121
                 float pc;

@@ -16,6 +16,10 @@
 #endif
 #define KAJO_KERNEL_NAME_BIG kajo_render_fast_big
 #define KAJO_KERNEL_NAME_BIGLIST kajo_render_fast_biglist
+// (an instance per home of the grid's cell lists -- LDS: _lg, global memory: the plain names -- as the STRICT / EXACT builds have since round 3:
+// one typed walk per kernel instead of both, round 6)
+#define KAJO_KERNEL_NAME_BIG_LG kajo_render_fast_big_lg
+#define KAJO_KERNEL_NAME_BIGLIST_LG kajo_render_fast_biglist_lg
 #define KAJO_KERNEL_NAME_SPLIT kajo_render_fast_split
 #define KAJO_KAT_SHADE_NAME kajo_kat_shade_fast
 #define KAJO_KAT_TRACE_NAME kajo_kat_trace_fast

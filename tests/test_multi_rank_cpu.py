@@ -87,3 +87,41 @@ def test_bench_starts_its_own_ranks():
     assert p.returncode != 0
     assert "bench.py needs a GPU" in p.stderr and "--nproc-per-node" not in p.stdout
     assert p.stderr.count("bench.py needs a GPU") >= 2 or "local_rank: 1" in p.stderr or "rank      : 1" in p.stderr
+
+
+def _bench(*extra):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", *extra],
+                          capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+
+
+def test_a_failed_multi_rank_run_still_prints_one_parseable_line():
+    """First contact with N > 1 hardware must be diagnosable (the 8-GPU run is the driver's, nobody watches it): when a rank fails --
+    here: a backend name torch.distributed does not know -- the run still ends in ONE JSON line with the contract's keys, value null,
+    the stage each rank had reached and the error; the exit code is not zero."""
+    import json
+    p = _bench("--backend", "no_such_backend")
+    assert p.returncode != 0
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["value"] is None and out["n_gpus"] == 2 and out["metric"] == "Msamples/s" and out["config"]["backend"] == "no_such_backend"
+    assert "init_process_group(no_such_backend)" in json.dumps(out["stage"]), out
+    assert out["error"] and ("no_such_backend" in out["error"].lower() or "no_such_backend" in (out.get("stderr_tail") or "").lower()), out
+    # every rank said where it was
+    assert p.stderr.count("KAJO_BENCH_STAGE") >= 2 and "KAJO_BENCH_ERROR" in p.stderr
+
+
+def test_a_run_without_gpus_names_the_stage():
+    """... and the same when the ranks come up but find no device (this container): stage 'device', the message of the product's refusal
+    to run on a CPU."""
+    import json
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = _bench("--backend", "gloo", "--gather-direct")
+    assert p.returncode != 0
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["value"] is None and "device" in json.dumps(out["stage"]) and "needs a GPU" in out["error"] and out["config"]["gather_direct"] is True

@@ -1410,6 +1410,11 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             cam[7] = DFloat4{__builtin_bit_cast(float, (uint32_t)dst), __builtin_bit_cast(float, (uint32_t)(dst >> 32)), __builtin_bit_cast(float, (uint32_t)cry),
                              __builtin_bit_cast(float, (uint32_t)(cry >> 32))};
             cam[2].w = __builtin_bit_cast(float, args.carrySlots);
+            // ... and the slot of the workgroup's first thread: a lane's slot is that plus its index in the workgroup (the SPLIT kernels: in
+            // its wave), formed again where the sums are written instead of living -- as a zero-extended 64-bit pair -- through the loop
+            cam[3].w = __builtin_bit_cast(float, (PARTS && part > 0) ? kajoSideSlot(blockIdx.x, args.partedFirst, (uint32_t)(args.nPasses / KAJO_GROUP_PASSES),
+                                                                                   (uint32_t)part, args.sideStride, blockDim.x, 0u)
+                                                                     : logicalBlock * (SPLIT ? 64u : blockDim.x));
         }
     }
     __syncthreads();
@@ -1458,6 +1463,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     constexpr bool LISTS_RMW = LISTS && KAJO_LISTS_TILE_RMW;
     // (PARTS kernels: `total` is the sum of the group of passes the lane is in; the running total waits in the lane's LDS word behind the mailbox)
     DFloat4* const accWord = mailbox + 64 * stealWindow + lane;
+    // (the same word, its address formed from the lane index again where a group ends -- once in a hundred paths -- and after the loop: the
+    // address as a loop-invariant vector register was what the instance of any number of lights spilled to scratch)
+    const auto accWordNow = [&]() -> DFloat4* {
+        uint32_t l = (uint32_t)lane; // (not threadIdx.x: the kernel's input register would have to live through the loop for it)
+        asm volatile("" : "+v"(l));
+        return mailbox + 64 * stealWindow + l;
+    };
     if (PARTS) {
         if (inImage) {
             float4 t = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -1702,8 +1714,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     if (PARTS) { // a group of passes complete
                         // (also when it was the last group: what is added after the loop is a zero then)
                         if (((ownPass - 1) & kGroupMask) == 0) { // (a group ends before pass p when (p - 1) % 4 == 0: passes are numbered from 1)
-                            const DFloat4 a = *accWord;
-                            *accWord = DFloat4{a.x + total.x, a.y + total.y, a.z + total.z, a.w};
+                            DFloat4* const aw = accWordNow();
+                            const DFloat4 a = *aw;
+                            *aw = DFloat4{a.x + total.x, a.y + total.y, a.z + total.z, a.w};
                             total = f3(0.0f, 0.0f, 0.0f);
                         }
                     }
@@ -2482,8 +2495,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         if (splitWave == 0 && inImage) {
             // (GROUPS: `group` is the sum of the group of passes p is in, `total` the total the complete groups have been added to)
             F3 group = f3(0.0f, 0.0f, 0.0f);
+            const uint32_t slotE = GROUPS ? __builtin_bit_cast(uint32_t, lds.camera[3].w) + (uint32_t)lane : slot;
             if (GROUPS && args.carryIn) {
-                const float4 t = reinterpret_cast<const float4*>(args.carry)[slot], g = reinterpret_cast<const float4*>(args.carry)[args.carrySlots + slot];
+                const float4 t = reinterpret_cast<const float4*>(args.carry)[slotE], g = reinterpret_cast<const float4*>(args.carry)[args.carrySlots + slotE];
                 total = f3(t.x, t.y, t.z);
                 totalW = t.w;
                 group = f3(g.x, g.y, g.z);
@@ -2518,12 +2532,12 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                 const DFloat4 c7 = lds.camera[7];
                 KajoGlobalVec4* const carry = KAJO_GLOBAL_VEC4(c7.z, c7.w);
                 if (carry) { // the launch ends inside a group
-                    carry[slot] = KajoVec4{total.x, total.y, total.z, totalW};
-                    carry[__builtin_bit_cast(uint32_t, lds.camera[2].w) + slot] = KajoVec4{group.x, group.y, group.z, 0.0f};
+                    carry[slotE] = KajoVec4{total.x, total.y, total.z, totalW};
+                    carry[__builtin_bit_cast(uint32_t, lds.camera[2].w) + slotE] = KajoVec4{group.x, group.y, group.z, 0.0f};
                 }
                 total = total + group;
             }
-            reinterpret_cast<float4*>(args.tiles)[slot] = make_float4(total.x, total.y, total.z, totalW);
+            reinterpret_cast<float4*>(args.tiles)[slotE] = make_float4(total.x, total.y, total.z, totalW);
         }
     } else if (!KAT && inImage) {
         if (LISTS_RMW) { // (the own passes' terms are in the buffer already)
@@ -2533,7 +2547,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
         // passes of this pixel that other lanes rendered, in pass order
         if (PARTS) {
-            DFloat4 a = *accWord;
+            const uint32_t slotE = __builtin_bit_cast(uint32_t, lds.camera[3].w) + waveInGroup * 64u + (uint32_t)lane; // (+ threadIdx.x, from what is live)
+            DFloat4 a = *accWordNow();
             for (int p = myEnd; p < lastPass; p++) {
                 if (p > myEnd && ((p - 1) & kGroupMask) == 0) { // (a group that ended with the lane's own last pass is in the word already)
                     a = DFloat4{a.x + total.x, a.y + total.y, a.z + total.z, a.w};
@@ -2545,13 +2560,13 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
             const DFloat4 c7 = lds.camera[7];
             KajoGlobalVec4* const carry = KAJO_GLOBAL_VEC4(c7.z, c7.w);
             if (carry) { // the launch ends inside a group (never a parted launch): its two summands wait for the next launch
-                carry[slot] = KajoVec4{a.x, a.y, a.z, a.w};
-                carry[__builtin_bit_cast(uint32_t, lds.camera[2].w) + slot] = KajoVec4{total.x, total.y, total.z, 0.0f};
+                carry[slotE] = KajoVec4{a.x, a.y, a.z, a.w};
+                carry[__builtin_bit_cast(uint32_t, lds.camera[2].w) + slotE] = KajoVec4{total.x, total.y, total.z, 0.0f};
             }
             total = f3(a.x + total.x, a.y + total.y, a.z + total.z); // the last group (a zero if it ended with a pass the lane rendered itself)
             totalW = a.w;
             // (the tile buffer, or the side buffer of a later part)
-            KAJO_GLOBAL_VEC4(c7.x, c7.y)[slot] = KajoVec4{total.x, total.y, total.z, totalW};
+            KAJO_GLOBAL_VEC4(c7.x, c7.y)[slotE] = KajoVec4{total.x, total.y, total.z, totalW};
         } else {
             for (int p = myEnd; p < lastPass; p++) {
                 const DFloat4 t = mailbox[lane * stealWindow + (p - stealBase)];
@@ -2562,8 +2577,8 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
     }
 #undef lastPass
 #undef stealBase
-    if (!KAT && !SPLIT && args.waveTrips && lane == 0)
-        args.waveTrips[slot >> 6] = trips;
+    if (!KAT && !SPLIT && args.waveTrips && lane == 0) // (the first launch of a handle: image order, no parts)
+        args.waveTrips[(PARTS ? __builtin_bit_cast(uint32_t, lds.camera[3].w) + waveInGroup * 64u : slot) >> 6] = trips;
 
     if (counting && lane == 0) {
         atomicAdd(&args.counters[0], ctrTraversals);

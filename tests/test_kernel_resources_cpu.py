@@ -54,10 +54,11 @@ def test_fast_kernels_keep_their_register_budgets_and_use_no_flat_accesses():
         r = res[k]
         assert r["Occupancy"] == 5 and r["VGPRs"] <= 96, (k, r)
         assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0 and r["ScratchSize"] == 0, (k, r)
-    # the large-scene kernels: four waves per SIMD; they spill scalars, vector spills stay a handful
-    for k in ("kajo_render_fast_big", "kajo_render_fast_biglist"):
+    # the large-scene kernels, an instance per home of the grid's cell lists (LDS: _lg): four waves per SIMD, no vector spills (one spilled
+    # VGPR cost the list kernel 2.4 GB of scratch traffic per launch in round 5); scalar spills 65 -> 44-46 in the list kernels (round 6)
+    for k in ("kajo_render_fast_big", "kajo_render_fast_biglist", "kajo_render_fast_big_lg", "kajo_render_fast_biglist_lg"):
         r = res[k]
-        assert r["Occupancy"] == 4 and r["VGPRs"] <= 128 and r["VGPRs Spill"] <= 8, (k, r)
+        assert r["Occupancy"] == 4 and r["VGPRs"] <= 116 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["SGPRs Spill"] <= 50, (k, r)
     # every pointer of these kernels has a known home (LDS or global): a flat access is an address space the compiler could not infer
     flat = [l.strip() for l in asm.splitlines() if re.match(r"\s+flat_(load|store|atomic)", l)]
     assert not flat, flat[:5]
@@ -121,15 +122,18 @@ def test_exact_kernels_keep_their_register_budgets():
     res, asm = _compile("exact")
     r = res["kajo_render_exact"]
     assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["SGPRs Spill"] <= 10, r
-    # (the instance of any number of lights spills a few registers: none of them inside a loop)
-    assert not _scratch_in_loops(asm, "kajo_render_exact_split")
-    r = res["kajo_render_exact_split"]
-    assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] <= 3, r
-    r = res["kajo_render_exact_lights"]
-    assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] <= 12, r
-    for k in ("kajo_render_exact_big", "kajo_render_exact_biglist", "kajo_render_exact_big_lg", "kajo_render_exact_biglist_lg"):
+    # Round 6: the instance of any number of lights (10 VGPRs / 28 bytes of scratch in round 5: +14 MB of HBM traffic per launch of the
+    # caustics scene, profiles/r06_notes.txt) and the small-frame kernel spill no vector register either -- what they parked were
+    # loop-invariant addresses (a lane's LDS word, its buffer slot as a 64-bit pair, threadIdx.x), now formed again where they are used.
+    for k in ("kajo_render_exact_split", "kajo_render_exact_lights"):
         r = res[k]
-        assert r["Occupancy"] == 4 and r["VGPRs"] <= 128 and r["VGPRs Spill"] <= 8, (k, r)
+        assert r["Occupancy"] == 5 and r["VGPRs"] <= 96 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["SGPRs Spill"] <= 16, (k, r)
+        assert not _scratch_in_loops(asm, k)
+    # large scenes: no vector spills; the scalar ones were 76 / 67 in the list kernels before the instances of scenes with visibility lists
+    # dropped the code of general sphere records, scaled planes and the every-sphere fallback (round 6)
+    for k, sgpr in (("kajo_render_exact_big", 44), ("kajo_render_exact_biglist", 62), ("kajo_render_exact_big_lg", 40), ("kajo_render_exact_biglist_lg", 60)):
+        r = res[k]
+        assert r["Occupancy"] == 4 and r["VGPRs"] <= 128 and r["VGPRs Spill"] == 0 and r["SGPRs Spill"] <= sgpr, (k, r)
     for k in res:
         if k.startswith("kajo_render_exact"):
             assert not re.search(r"\n\s+flat_(load|store|atomic)", _body(asm, k)), k

@@ -637,7 +637,7 @@ def run_ranks(args, world, rank, local_rank):
         # the parity legs first, the timed CPU baseline last (its libraries are built with the reference's fast-math flags)
         if sched_leg:
             # hip::Scheduler::run() on the same frame with the same numerics build, next to ms_per_step: the difference is the 8 MB
-            # host read-back and the synchronous refresh
+            # host read-back and the synchronous refresh (PCIe-inclusive rate)
             out["scheduler_run"] = sched_leg
         # Every numerics build on the timed frame against the CPU oracle's rendering of THAT frame (all of its pixels).
         want, oracle_s = oracle_frame(scene, W, H, PASSES)

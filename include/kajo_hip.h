@@ -65,10 +65,10 @@ extern "C" {
 #define KAJO_FLAG_COUNTERS 2u /* maintain device-side work counters */
 #define KAJO_FLAG_NO_GRID 4u  /* always walk every sphere (no uniform grid for large scenes) */
 #define KAJO_FLAG_NO_REORDER 8u /* dispatch workgroups in image order (no cost-sorted launch order) */
-#define KAJO_FLAG_COOP 32u      /* EXPERIMENT, round 2 (measured slower; only in kajo_amd/libkajo_hip_r02.so of `make
+#define KAJO_FLAG_COOP 32u      /* EXPERIMENT, round 2 (measured slower, profiles/HISTORY.md section 8; only in kajo_amd/libkajo_hip_r02.so of `make
                                    experiments`, refused by the product library): the 8 waves of a workgroup pool their rays in LDS every
                                    trip, counting-sort them by kind and octant into a compact queue and walk that */
-#define KAJO_FLAG_DEFERRED 64u  /* EXPERIMENT, round 3 (measured slower; only in kajo_amd/libkajo_hip_exp.so of `make
+#define KAJO_FLAG_DEFERRED 64u  /* EXPERIMENT, round 3 (measured slower, profiles/HISTORY.md section 8; only in kajo_amd/libkajo_hip_exp.so of `make
                                    experiments`, refused by the product library): surviving vertices are parked in LDS and the light / BSDF
                                    sampling blocks run only in trips where enough lanes have one (deferred.inc.hip) */
 #define KAJO_FLAG_NO_SPLIT 16u  /* small frames: do not let several waves share a pixel block and divide the passes; large frames

@@ -273,7 +273,7 @@ void Scheduler::run()
     std::vector<double> batchMs;
     std::vector<int> batchPasses;
     // Passes between two refreshes. Fusing passes into one launch evens out the lanes' trip counts (38 G paths/s at
-    // 16 per launch against 30 at one), so headless runs take all that is left and a live preview
+    // 16 per launch against 30 at one, profiles/HISTORY.md section 6), so headless runs take all that is left and a live preview
     // gets as many as fit a 30 Hz refresh, from the measured time per pass.
     // A launch cannot be interrupted (the reference's workers look at their stop flag once per row, cpu/Renderer.cpp:77-78): the
     // bound on how long run() can overshoot a closed window -- or a caller waits for the first image -- is the length of one

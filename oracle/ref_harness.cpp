@@ -12,7 +12,7 @@
 // libraries are kept out of git history (.gitignore) but DO travel to the GPU box with the
 // snapshot, like this repo's own built .so files, so that tests and bench.py there can check
 // against, and time, the reference itself (cpu_baseline.kind "reference"); the reference's
-// SOURCES never leave /root/reference. ("What travels".)
+// SOURCES never leave /root/reference. (profiles/HISTORY.md section 2, "What travels to the GPU box".)
 //
 // Per-sample stream protocol: the 128-bit cpu::Random state is
 // overwritten (16 bytes at offset 0 of the object; Random derives from the empty

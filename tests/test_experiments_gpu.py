@@ -45,7 +45,7 @@ COOP = textwrap.dedent("""
 
 @needs_r02
 def test_cooperative_sorted_traversal_is_result_identical():
-    """KAJO_FLAG_COOP (round 2): the 8 waves of a workgroup pool their rays in LDS every trip, counting-sort
+    """KAJO_FLAG_COOP (round 2, profiles/HISTORY.md section 8): the 8 waves of a workgroup pool their rays in LDS every trip, counting-sort
     them by ray kind and octant into a compact queue, and every lane walks the ray at its queue position. Which lane walks a ray
     does not change its arithmetic: STRICT stays the oracle bit for bit, FAST stays FAST. Measured slower; not shipped."""
     env = dict(os.environ, KAJO_HIP_LIB=LIB)
@@ -127,7 +127,7 @@ DEFERRED = textwrap.dedent("""
 
 @needs_exp
 def test_deferred_shading_is_result_identical():
-    """KAJO_FLAG_DEFERRED (round 3): surviving vertices are parked in an LDS stash and the light / BSDF blocks
+    """KAJO_FLAG_DEFERRED (round 3, profiles/HISTORY.md section 8): surviving vertices are parked in an LDS stash and the light / BSDF blocks
     run only in trips where enough lanes have one; paths of a pixel complete out of order and are retired in sample order through a
     ring. STRICT stays the oracle bit for bit for several stash / ring / threshold settings; FAST stays within SURVEY section
     8c's frame tolerances of the product's FAST (the same formulas compiled in another loop: contraction differs). Measured slower (the stash costs occupancy, and throughput follows waves per SIMD); not shipped."""

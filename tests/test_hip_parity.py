@@ -99,10 +99,9 @@ def test_builtin_test_scene_strict(O):
 def test_grid_walk_equals_brute_force(O, scenes):
     """Large scenes reach their spheres through a uniform grid (3D-DDA); the closest hit and the tie rule
     must be those of the walk over every sphere: STRICT grid == oracle (which tests every sphere) bit for
-    bit. FAST grid == FAST brute force bit for bit ON THESE SCENES: the per-sphere arithmetic is the same, but the FAST grid
-    walk accepts a sphere only when strictly closer (three instructions less per test), so two DIFFERENT
-    objects at a bit-identical distance -- a sphere and a plane, or two spheres -- go to the one met first there and to the later
-    object in the every-object walk; no such tie occurs among these scenes' rays. (STRICT keeps the reference's rule everywhere.)"""
+    bit. FAST grid == FAST brute force bit for bit: the same per-sphere arithmetic, and since round 5 the same tie rule -- the grid walk
+    compares (distance pattern, ~index) as one 64-bit key, so that of two objects at a bit-identical distance the later one wins whatever
+    order the cells deliver them in (tests/test_hip_ties.py constructs such ties)."""
     from kajo_amd import capi
     base = scenes["spheres_a169"]
     for sc, W, H in ((stress_scene(base, 300, 6, seed=7), 96, 54), (stress_scene(base, 1000, 16), 64, 36)):

@@ -4,7 +4,7 @@ bounds promise, no spills in the small-scene loops, and no FLAT memory instructi
 Why a test: both have regressed silently before. A `volatile` access through a generic pointer compiles to `flat_load` /
 `flat_store` with system scope and a `vmcnt(0)` wait (the compiler does not infer the LDS address space for volatile accesses) --
 the large-scene kernels' list walk carried five of those per round for most of round 4 -- and one more scalar value live across the
-small-scene loop spills five registers (-1.4 %). The command is the Makefile's own (`make -n`), with the
+small-scene loop spills five registers (-1.4 %, profiles/HISTORY.md section 4.2). The command is the Makefile's own (`make -n`), with the
 assembly and the resource remarks asked for instead of an object file."""
 import os
 import re
@@ -144,7 +144,7 @@ def test_exact_kernels_keep_their_register_budgets():
 
 # Static VALU instruction counts of the small-scene kernels (the whole kernel, loops counted once), from the compiler's assembly of the
 # Makefile's own command. The loop's time follows its VALU instruction count (STRICT / FAST: 2.28 x the instructions, 2.26 x the time,
-# DESIGN.md section 4.3), and round 4 lost 2-3 % twice to changes that "only" added instructions to it (commit 8218d68). A change that
+# profiles/HISTORY.md section 4.3), and round 4 lost 2-3 % twice to changes that "only" added instructions to it (commit 8218d68). A change that
 # adds more than ~3 % has to raise its budget here, knowingly. Measured at the time of writing: 1396, 1360, 2227, 2471, 2766, 3003
 # (the STRICT / EXACT kernels carry two sphere loops and two plane loops since round 5 -- the ones for scenes of (centre, radius) spheres
 # and rigid planes, +7 % / +6.5 %, and the general ones: ~170-250 instructions more in the text, fewer executed).

@@ -1,20 +1,57 @@
 #!/bin/bash
-# Copy what tools/profile_round.sh left under gpurun_out/<tag>prof/ into profiles/ (the files the docs cite).
-R=${1:-r04}; P=gpurun_out/${R}prof
-[ -f $P/bench_final.json ] && cp $P/bench_final.json profiles/${R}_bench.json || cp $P/bench.json profiles/${R}_bench.json
-grep -v amdgpu.ids $P/configs.txt > profiles/${R}_configs.txt
-cp $P/pmc_fast.txt profiles/${R}_pmc_fast.txt; cp $P/pmc_strict.txt profiles/${R}_pmc_strict.txt; cp $P/counters.json profiles/${R}_counters.json
-[ -f $P/size_sweep.txt ] && grep -v amdgpu.ids $P/size_sweep.txt > profiles/${R}_size_sweep.txt
-for k in fast strict; do f=$(ls -t $P/stats_$k/*/*kernel_stats.csv | head -1); cp $f profiles/${R}_bench_kernel_stats_$k.csv; done
-for k in fast strict fast_stress strict_stress; do [ -f $P/blockprof_$k.txt ] && grep -v amdgpu.ids $P/blockprof_$k.txt > profiles/${R}_blockprof_$k.txt; done
-[ -f $P/rank_share.txt ] && grep -v amdgpu.ids $P/rank_share.txt > profiles/${R}_rank_share_table.txt
-python3 - <<PY
-import json
-d=json.loads(open('profiles/${R}_bench.json').read().strip().splitlines()[-1])
-print('FAST %.1f M paths/s, %.2f ms/step, kernel %.2f ms, frac %.4f, traffic %s, executed %.1f TF'%(d['value'],d['ms_per_step'],d['roofline']['kernel_ms_per_launch'],d['roofline']['frac'],d['roofline']['traffic'],(d['roofline'].get('executed_flops') or {}).get('tflops',0)))
-n=d['north_star_mode']; print('north star: %s %.1f, %.0fx, %d/%d px'%(n['numerics'],n['value'],n['speedup_vs_cpu_baseline'],n['bit_identical_px'],n['px']))
-print('cpu ref %.1f port %.1f speedup %.0f hash %s'%(d['cpu_baseline']['value'],d['cpu_baseline']['port']['value'],d['speedup_vs_cpu_baseline'],d['config']['kernel_source_hash']))
-c=json.load(open('profiles/${R}_counters.json'))
-for k,v in c.items(): print(k,'util %.3f'%v['valu_lane_utilisation'],'hbm',v['hbm_bytes_per_launch'],v['kernel_source_hash'],'valu %.3e'%v['counters_per_launch']['SQ_INSTS_VALU'])
+# Build side: copy what tools/profile_round.sh <tag> a|b|c left under gpurun_out/<tag>prof/ (merged back by gpurun) into profiles/ under the
+# round's names -- the files the docs cite.   usage: tools/collect_round.sh <tag> [counters]
+#   counters: only merge the PMC summaries of stages a and b into profiles/<tag>_counters.json (what stage c's bench line reads)
+cd "$(dirname "$0")/.." || exit 1
+R=${1:?round tag}; P=gpurun_out/${R}prof
+python3 - "$R" <<'PY'
+import json, os, sys
+R = sys.argv[1]
+a = {}
+what = {"exact": ("c2", ""), "fast": ("c2", " --fast"), "strict": ("c2", " --strict"), "c4_exact": ("c4", None), "c5_exact": ("c5", None), "c5_fast": ("c5", None)}
+for tag, (wl, flag) in what.items():
+    path = "gpurun_out/pmc/%s_%s/counters.json" % (R, tag)
+    if not os.path.exists(path):
+        print("missing", path)
+        continue
+    for k, d in json.load(open(path)).items():
+        d["workload"] = wl
+        cmd = ("python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline" + flag) if flag is not None else ("python3 tools/launch_workload.py " + tag.replace("_", " "))
+        d["collected"] = ("round %s, MI355X, rocprofv3 --kernel-trace --pmc (six separate passes, tools/pmc.sh / tools/pmc_workload.sh; per counter the median over "
+                          "the dispatches of a pass) over " % R) + cmd
+        a[k] = d
+json.dump(a, open("profiles/%s_counters.json" % R, "w"), indent=1, sort_keys=True)
+for k, d in sorted(a.items()):
+    print("%-32s %s lane utilisation %.3f, SALU/VALU %.3f, HBM %.1f MB per launch, source %s" % (k, d["workload"], d.get("valu_lane_utilisation", 0), d.get("salu_per_valu", 0),
+          d.get("hbm_bytes_per_launch", 0) / 1e6, d.get("kernel_source_hash")))
 PY
-head -2 profiles/${R}_bench_kernel_stats_fast.csv | tail -1 | cut -c1-60; head -2 profiles/${R}_bench_kernel_stats_strict.csv | tail -1 | cut -c1-60; cut -c1-100 profiles/${R}_configs.txt
+[ "$2" = counters ] && exit 0
+clean() { grep -v amdgpu.ids "$1" > "$2"; }
+[ -f $P/bench_final.json ] && cp $P/bench_final.json profiles/${R}_bench.json || cp $P/bench.json profiles/${R}_bench.json
+for m in exact fast strict; do
+  f=$(ls -t $P/stats_$m/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_bench_kernel_stats_$m.csv
+  [ -f $P/steady_$m.csv ] && cp $P/steady_$m.csv profiles/${R}_bench_kernel_steady_$m.csv
+  [ -f $P/pmc_$m.txt ] && clean $P/pmc_$m.txt profiles/${R}_pmc_$m.txt
+done
+for t in c4_exact c5_exact c5_fast; do
+  [ -f $P/pmc_$t.txt ] && clean $P/pmc_$t.txt profiles/${R}_pmc_$t.txt
+  f=$(ls -t gpurun_out/pmc/${R}_$t/stats/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" profiles/${R}_kernel_stats_$t.csv
+done
+for f in blockprof_exact blockprof_fast blockprof_strict blockprof_exact_caustics blockprof_fast_stress blockprof_exact_stress configs rank_share size_sweep; do
+  [ -f $P/$f.txt ] && clean $P/$f.txt profiles/${R}_$f.txt
+done
+[ -f $P/configs_roofline.json ] && cp $P/configs_roofline.json profiles/${R}_configs_roofline.json
+[ -f gpurun_out/${R}_parity_workloads.json ] && cp gpurun_out/${R}_parity_workloads.json profiles/${R}_parity_workloads.json
+python3 - "$R" <<'PY'
+import json, sys
+R = sys.argv[1]
+d = json.loads(open("profiles/%s_bench.json" % R).read().strip().splitlines()[-1])
+print("%s %.1f M paths/s, %.2f ms/step, kernel %.2f ms, frac %.4f, traffic %s" % (d["config"]["numerics"], d["value"], d["ms_per_step"], d["roofline"]["kernel_ms_per_launch"],
+      d["roofline"]["frac"], d["roofline"]["traffic"]))
+for m in ("fast_mode", "strict_mode", "exact_mode"):
+    if m in d:
+        print("  %s %.1f M paths/s, kernel %.2f ms, frac %.4f" % (m, d[m]["value"], d[m]["kernel_ms_per_launch"], d[m]["roofline"]["frac"]))
+if d.get("cpu_baseline"):
+    print("cpu reference %.1f M paths/s on %d cores, x %.0f" % (d["cpu_baseline"]["value"], d["cpu_baseline"]["cores"], d["speedup_vs_cpu_baseline"]))
+PY
+for m in exact fast strict; do [ -f profiles/${R}_bench_kernel_steady_$m.csv ] && tail -n +2 profiles/${R}_bench_kernel_steady_$m.csv; done

@@ -139,11 +139,10 @@ struct KajoHip
     int thrL = 1, holdTrips = 1; // integrator.inc.hip MODE_HOLD
     int ldsExtra = 0;    // (KAJO_TUNING builds only) unused bytes per wave, to study a launch at a lower occupancy
     int helpBytes = 0;   // list scenes: [64] owner lanes + [64] blocker flags of the cooperative list walk (integrator.inc.hip), behind the mailbox
-    int stashBytes = 0;  // (-DKAJO_STASH=1 experiment builds only: [7][64] words, the lanes' parked camera rays, behind the running totals)
     int accBytes = 0;    // FAST / EXACT, small scenes: [64] float4, the lanes' running totals behind the mailbox (integrator.inc.hip GROUPS)
     size_t perWaveBytes(bool withMailbox) const
     {
-        return (size_t)ldsExtra + (size_t)helpBytes + (withMailbox ? (size_t)64 * stealWindow * 16 + (size_t)accBytes + (size_t)stashBytes : 0);
+        return (size_t)ldsExtra + (size_t)helpBytes + (withMailbox ? (size_t)64 * stealWindow * 16 + (size_t)accBytes : 0);
     }
     void fillWaveLds(RenderArgs& a, size_t perWaveOffset, bool withMailbox) const
     {
@@ -687,10 +686,6 @@ int kajo_hip_create(const KajoScene* scene, int width, int height, const KajoPar
         h->stealWindow = 3;
         KAJO_TUNE_INT("KAJO_STEAL_WINDOW", 1, 16, h->stealWindow);
     }
-#if defined(KAJO_STASH) && KAJO_STASH
-    if (h->coldInLds)
-        h->stashBytes = 7 * 64 * 4;
-#endif
     h->ldsBytes = hotBytes + (h->coldInLds ? coldBytes : 0) + gridHeaderBytes + gridBytes;
     // every workgroup stages its own LDS copy of the scene: single-wave groups only while that copy is small
     h->wavesPerBlock = h->ldsBytes <= 6 * 1024 ? 1 : 4;

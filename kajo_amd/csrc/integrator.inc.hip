@@ -1213,9 +1213,6 @@ enum : int
 #ifndef KAJO_ANY_LANE_GIVES
 #define KAJO_ANY_LANE_GIVES 1 // 0: only lanes that are themselves between two paths in this trip can give a pass away (rounds 2-5)
 #endif
-#ifndef KAJO_STASH
-#define KAJO_STASH 0 // 1: the camera-ray stash experiment of round 6 (renderBody STASH; capi.cpp reserves its LDS under the same macro)
-#endif
 #ifndef KAJO_LISTS_BALANCED
 #define KAJO_LISTS_BALANCED 1 // 0: the light loop of rounds 4 (one vertex per lane), for A/B runs
 #endif
@@ -1597,47 +1594,10 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
 #endif
     uint32_t trips = 0;
     int heldTrips = 0; // (wave-uniform) consecutive trips in which some lane wanted the light / BSDF blocks and they did not run
-    // STASH (an experiment of round 6, -DKAJO_STASH=1; measured in profiles/r06_notes.txt, not in the product): the camera-ray block -- a
-    // fifth of a trip's instructions, run in 96 % of the trips with half of the lanes -- treated as an occupancy problem. Whenever the block
-    // runs, every lane that is in the middle of a path and has no ray in store forms the camera ray of its NEXT path too (stream key, jitter
-    // draw, direction: the same arithmetic on the same operands) and parks it in seven LDS words of its own; a lane that starts a path
-    // takes the parked ray if it has one, and the block runs only in trips in which some lane starts a path without one.
-    constexpr bool STASH = KAJO_STASH && !KAT && !SPLIT && COLD_LDS && !LISTS;
-    float* const stashWords = reinterpret_cast<float*>(mailbox + 64 * stealWindow + (PARTS ? 64 : 0)) + lane; // [7][64] words, word k of the lane at k * 64
-    int stashState = 0; // 0: nothing parked; 1: the next sample of the pass being rendered; 2: the first sample of the lane's next own pass
     for (;;) {
         trips++;
         KAJO_STAMP(4); // tail of the previous trip (path bookkeeping, loop back-edge)
         // ---- MODE_NEW: camera ray of the next sample (Renderer.cpp:51-64) ---------------------
-        if (STASH && mode == MODE_NEW && stashState != 0) {
-            if (stashState == 2) { // the parked ray opens the lane's next pass: the one it has just finished is complete (Renderer.cpp:70-71)
-#if KAJO_RSTRICT
-                const F3 term = f3(kdiv(radiance.x, args.S), kdiv(radiance.y, args.S), kdiv(radiance.z, args.S));
-#else
-                const F3 term = radiance * invS;
-#endif
-                total = total + term;
-                ownPass++;
-                if (PARTS && ((ownPass - 1) & kGroupMask) == 0) {
-                    const DFloat4 a = *accWord;
-                    *accWord = DFloat4{a.x + total.x, a.y + total.y, a.z + total.z, a.w};
-                    total = f3(0.0f, 0.0f, 0.0f);
-                }
-                radiance = f3(0.0f, 0.0f, 0.0f);
-            }
-            rng.lo = (uint64_t)__builtin_bit_cast(uint32_t, stashWords[0]) | ((uint64_t)__builtin_bit_cast(uint32_t, stashWords[64]) << 32);
-            rng.hi = (uint64_t)__builtin_bit_cast(uint32_t, stashWords[128]) | ((uint64_t)__builtin_bit_cast(uint32_t, stashWords[192]) << 32);
-            d = f3(stashWords[256], stashWords[320], stashWords[384]);
-            const DFloat4 c3 = lds.camera[3];
-            O = f3(c3.x, c3.y, c3.z);
-            L = f3(0.0f, 0.0f, 0.0f);
-            T = f3(1.0f, 1.0f, 1.0f);
-            depth = 0;
-            collectEmission = true;
-            pendBsdf = false;
-            stashState = 0;
-            mode = MODE_EXTEND;
-        }
         KAJO_PROF(0, mode == MODE_NEW);
         if (KAT && mode == MODE_NEW) {
             if (katStarted) {
@@ -1664,9 +1624,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         const auto takeOverPasses = [&]() {
             unsigned long long idleMask = __ballot(mode == MODE_NEW && stolenFrom < 0 && ownPass >= myEnd);
             while (idleMask) { // wave-uniform; only in the last stretch of the wave's life
-                const int give = myEnd - 1; // the pass this lane could give away (a parked camera ray of the next pass has begun it)
+                const int give = myEnd - 1; // the pass this lane could give away
                 const unsigned long long giverMask = __ballot((ANY_GIVES || mode == MODE_NEW) && mode != MODE_DONE && stolenFrom < 0 &&
-                                                              give > ownPass + (STASH && stashState == 2 ? 1 : 0) && give >= stealBase);
+                                                              give > ownPass && give >= stealBase);
                 if (giverMask == 0ull) {
                     if (mode == MODE_NEW && stolenFrom < 0 && ownPass >= myEnd)
                         mode = MODE_DONE;
@@ -1731,28 +1691,9 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
         }
         if (!KAT && ANY_GIVES)
             takeOverPasses();
-        // (STASH: in a trip in which the block runs -- some lane starts a path empty-handed -- the lanes in the middle of a path of their own
-        // pixel park the ray of their next one: the next sample of the pass, or the first of the next own pass, whose number `pass` then
-        // takes at once -- a path of one's own pixel does not read it again)
-        bool parks = false;
         {
             const bool starts = !KAT && mode == MODE_NEW && (stolenFrom >= 0 || ownPass < myEnd);
-            if (STASH) {
-                const bool blockRuns = __ballot(mode == MODE_NEW) != 0ull; // (lanes that retire this trip count: their wave is near its end)
-                if (blockRuns && (mode == MODE_EXTEND || mode == MODE_SHADOW || mode == MODE_HOLD) && stashState == 0 && stolenFrom < 0) {
-                    if (!(sampleY == endY && sampleX == endX)) {
-                        parks = true;
-                        stashState = 1;
-                    } else if (ownPass + 1 < myEnd) {
-                        parks = true;
-                        stashState = 2;
-                        pass = ownPass + 1;
-                        sampleX = 0;
-                        sampleY = 0;
-                    }
-                }
-            }
-            if (starts || parks) {
+            if (starts) {
                 // The pixel whose pass the lane is rendering: its own, or the one of the lane it took the pass over from (same
                 // 8x8 block). Its stream key word and x * pixelWidth, (H - y) * pixelHeight of Renderer.cpp:56-57 are formed here
                 // rather than carried in six registers through the whole loop.
@@ -1783,25 +1724,15 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                     sampleX = 0;
                     sampleY++;
                 }
-                if (STASH && parks) {
-                    stashWords[0] = __builtin_bit_cast(float, (uint32_t)fresh.lo);
-                    stashWords[64] = __builtin_bit_cast(float, (uint32_t)(fresh.lo >> 32));
-                    stashWords[128] = __builtin_bit_cast(float, (uint32_t)fresh.hi);
-                    stashWords[192] = __builtin_bit_cast(float, (uint32_t)(fresh.hi >> 32));
-                    stashWords[256] = nd.x;
-                    stashWords[320] = nd.y;
-                    stashWords[384] = nd.z;
-                } else {
-                    rng = fresh;
-                    d = nd;
-                    O = camOrigin;
-                    L = f3(0.0f, 0.0f, 0.0f);
-                    T = f3(1.0f, 1.0f, 1.0f);
-                    depth = 0;
-                    collectEmission = true;
-                    pendBsdf = false;
-                    mode = MODE_EXTEND;
-                }
+                rng = fresh;
+                d = nd;
+                O = camOrigin;
+                L = f3(0.0f, 0.0f, 0.0f);
+                T = f3(1.0f, 1.0f, 1.0f);
+                depth = 0;
+                collectEmission = true;
+                pendBsdf = false;
+                mode = MODE_EXTEND;
             }
         }
         int aliveCount;

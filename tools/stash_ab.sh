@@ -1,4 +1,5 @@
 #!/bin/bash
+# (The stash variant is built from commit 075eefd -- the experiment was removed from the source afterwards: git worktree add /tmp/stash 075eefd, tools/build_variant.sh there.)
 # GPU box, round 6: (1) any lane may give a pass away (integrator.inc.hip KAJO_ANY_LANE_GIVES; variant oldgive = rounds 2-5: only lanes between
 # two paths), (2) the camera-ray stash experiment (STASH; variant stash: KFLAGS=-DKAJO_STASH=1) -- against the product's kernels (the tools'
 # twin). Correctness of the stash variant first (STRICT = oracle bit for bit, EXACT ends every path in the oracle's generator state, any

@@ -148,3 +148,39 @@ def test_kajo_render_batches_do_not_change_the_frame(tmp_path, numerics):
         os.remove(raw)
     for name, f in frames.items():
         assert np.array_equal(bits(f), bits(frames["16"])), (numerics, name)
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_four_wave_workgroups_with_a_parted_tail(scenes, mode):
+    """A scene whose LDS copy exceeds 6 KB runs four-wave workgroups that share one copy (capi.cpp wavesPerBlock): 30 spheres / 2 lights,
+    no grid. The parted tail's side-buffer slots, the slot base in LDS and the lanes' running totals are per WORKGROUP there: the same
+    cuts, parts and orders must give one buffer; STRICT of the same scene is the oracle on a small frame."""
+    from kajo_amd.scene import stress_scene
+    sc = stress_scene(scenes["spheres_a169"], 30, 2, seed=11)
+    kw = dict(exact=True) if mode == "exact" else {}
+    want, tail = render_cuts(sc, 1280, 720, (16,), warm=1, **kw)
+    assert tail > 0 and tail % 3 == 0  # parted: 3 more workgroups per parted block of a 16-pass launch
+    for cuts in ((8, 8), (1, 2, 13), (12, 4)):
+        got, _ = render_cuts(sc, 1280, 720, cuts, warm=1, **kw)
+        assert np.array_equal(bits(got), bits(want)), (mode, cuts)
+    for flags in (capi.KAJO_FLAG_NO_SPLIT, capi.KAJO_FLAG_NO_REORDER):
+        got, tail = render_cuts(sc, 1280, 720, (16,), warm=1, flags=flags, **kw)
+        assert tail == 0 and np.array_equal(bits(got), bits(want)), (mode, flags)
+
+
+def test_four_wave_workgroups_strict_is_the_oracle(scenes):
+    from kajo_amd.scene import stress_scene
+    from oraclelib import OracleLib, available
+    if not available("oracle"):
+        pytest.skip("oracle not built")
+    sc = stress_scene(scenes["spheres_a169"], 30, 2, seed=11)
+    W, H, P = 160, 90, 3
+    want = OracleLib("oracle").create(sc, 1).render(W, H, S=16, passes=P, seed=SEED, depth_limit=8)
+    with HipRenderer(sc, W, H, spp=16, seed=SEED, strict=True) as r:
+        got = r.render(P).radiance()
+    same = (bits(got[..., :3]) == bits(want[..., :3])) | (np.isnan(got[..., :3]) & np.isnan(want[..., :3]))
+    assert same.all(), int((~same).sum())
+    with HipRenderer(sc, W, H, spp=16, seed=SEED, exact=True) as r:
+        ex = r.render(P).radiance()
+    from exact_tol import assert_exact_within_tolerance
+    assert_exact_within_tolerance(ex, want, P, "30 spheres / 2 lights")

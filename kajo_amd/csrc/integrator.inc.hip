@@ -890,6 +890,58 @@ KDEV bool listWalkCooperative(const DSceneView& sc, const LdsScene& lds, KajoLds
     return hasQ && (blocked || helpFlag[lane] != 0u); // (a helper's `blocked` is about somebody else's query)
 }
 
+// Two stages (verdict item 2b of round 5 / round 5's own note: "a round is as long as its longest list"): every owner tests the first
+// KAJO_LIST_STAGE1 items of its list itself -- most queries end there, at their first blocker or at the first item beyond the ray's reach
+// --, then the lanes whose queries are answered take over the rest of the lists still open, shared out by the cooperative walk above.
+// 0 = the cooperative walk alone. Which lane tests an item does not change the test: the answer is the same.
+#ifndef KAJO_LIST_STAGE1
+#define KAJO_LIST_STAGE1 3 // measured on configs[4], 4K x 32 (profiles/r06_notes.txt): 0 -> 6 894 / 5 074 / 4 510 M paths/s FAST / EXACT / STRICT, 2 -> 7 131 / 5 117 / 4 691, 3 -> 7 160-7 212 / 5 152-5 179 / 4 660-4 690, 4 -> 7 158 / 5 155 / 4 662, 6 -> 7 112 / 5 087 / 4 576
+#endif
+KDEV bool listWalk(const DSceneView& sc, const LdsScene& lds, KajoLdsWord* helpOwner, KajoLdsWord* helpFlag, const uint32_t* items, int lane, bool hasQ,
+                   bool canHelp, F3& O, F3& d, uint32_t keyL, uint32_t k0, uint32_t e, int si, uint32_t reachQ)
+{
+    if (KAJO_LIST_STAGE1 == 0)
+        return listWalkCooperative(sc, lds, helpOwner, helpFlag, items, lane, hasQ, canHelp, O, d, keyL, k0, e, si, reachQ);
+    bool blocked = false, open = false;
+    uint32_t j = k0;
+    if (hasQ) {
+        const float aT = dot(d, d);
+#if KAJO_STRICT
+        const float iaT = 0.0f;
+#else
+        const float iaT = krcp(aT);
+#endif
+        open = true;
+        uint32_t nxt = j < e ? items[j] : 0xffffffffu;
+        for (int t = 0; t < KAJO_LIST_STAGE1; t++) {
+            if (j >= e) {
+                open = false;
+                break;
+            }
+            const uint32_t cur = nxt;
+            j++;
+            if (j < e)
+                nxt = items[j];
+            if ((cur >> 16) > reachQ) { // nothing further along the list can touch the ray before it ends
+                open = false;
+                break;
+            }
+            KAJO_COUNT_TESTS(lds, 1);
+            if (shadowItemBlocks(sc, lds, (int)(cur & 0xffffu), si, O, d, aT, iaT, keyL)) {
+                blocked = true;
+                open = false;
+                break;
+            }
+        }
+        open = open && j < e;
+    }
+    if (__ballot(open) == 0ull)
+        return hasQ && blocked;
+    // (a lane whose own query is answered -- or that never had one -- has dead ray registers: it may help)
+    const bool rest = listWalkCooperative(sc, lds, helpOwner, helpFlag, items, lane, open, canHelp && !open, O, d, keyL, j, e, si, reachQ);
+    return hasQ && (blocked || rest);
+}
+
 // ---- surface point of an accepted hit ------------------------------------------------------
 struct Surface
 {
@@ -2053,7 +2105,7 @@ KDEV void renderBody(const RenderArgs& args, unsigned char* ldsRaw)
                         }
                     }
                     KAJO_STAMP(6);
-                    const bool blocked = listWalkCooperative(sc, lds, helpOwner, helpFlag, items, lane, hasQ, canHelp, O, d, keyL, k0, e, si, reachQ);
+                    const bool blocked = listWalk(sc, lds, helpOwner, helpFlag, items, lane, hasQ, canHelp, O, d, keyL, k0, e, si, reachQ);
                     KAJO_STAMP(7);
                     // ---- (C) answers back to the vertices' owners, in light order
                     const bool reached = hasQ && !blocked;

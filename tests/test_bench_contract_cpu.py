@@ -33,10 +33,11 @@ def test_fields_and_arithmetic():
     # groups to the side buffers -- 7.9 MB, half the dispatches the counters saw were parted -- and nothing else: no scratch)
     assert r["traffic"] is not None and 1.0 <= r["traffic"] / r["hbm"]["algorithmic_bytes_per_launch"] < 1.2
     # the committed rocprofv3 summary of the same kernel agrees with the HIP-event time of the line: the steady-state median (a handle's
-    # first launches left out, tools/steady_stats.py) within 1 % of it and not above the driver-timed step
+    # first launches left out, tools/steady_stats.py) within 1 % of it, and -- another run of the command, under the tracer -- not above
+    # the driver-timed step by more than run-to-run variation (0.3 %; round 5's all-dispatch average stood 2 % above it)
     steady = open(os.path.join(ROOT, "profiles", "r06_bench_kernel_steady_exact.csv")).read().strip().splitlines()[-1].split(",")
     assert steady[0] == "kajo_render_exact" and int(steady[3]) >= 30
-    assert abs(float(steady[5]) / r["kernel_ms_per_launch"] - 1) < 0.01 and float(steady[5]) <= d["ms_per_step"]
+    assert abs(float(steady[5]) / r["kernel_ms_per_launch"] - 1) < 0.01 and float(steady[5]) <= 1.003 * d["ms_per_step"] and float(steady[6]) <= d["ms_per_step"]
     c = d["cpu_baseline"]
     assert c["kind"] == "reference" and c["unit"] == "Msamples/s" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["speedup_vs_cpu_baseline"] - d["value"] / c["value"]) < 1e-6 * d["speedup_vs_cpu_baseline"]

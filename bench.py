@@ -303,8 +303,8 @@ def free_port():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)  # (the first launches of a handle measure and order its blocks: five untimed steps leave them behind)
     ap.add_argument("--workload", default="auto", choices=["auto", "c2", "c3"],
                     help="auto: c2 (1080p, 16 passes) on one GPU, c3 (4K, 64 passes, strong scaling) on several")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline / parity / other-mode legs")

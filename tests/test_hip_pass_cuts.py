@@ -184,3 +184,28 @@ def test_four_wave_workgroups_strict_is_the_oracle(scenes):
         ex = r.render(P).radiance()
     from exact_tol import assert_exact_within_tolerance
     assert_exact_within_tolerance(ex, want, P, "30 spheres / 2 lights")
+
+
+@pytest.mark.parametrize("mode", ["fast", "exact"])
+def test_random_cuts_and_launch_sizes(scenes, mode):
+    """Seeded fuzz: 24 passes cut at random into render calls, with random passesPerLaunch (so that a call is itself cut into launches that
+    begin and end anywhere in a group), on a frame the SPLIT kernels render and on one the unsplit kernels render with a parted tail."""
+    sc = scenes["caustics_a169"]  # three lights: the instances of any number of lights
+    kw = dict(exact=True) if mode == "exact" else {}
+    rng = np.random.default_rng(20261005 if mode == "exact" else 5)
+    for W, H, cases in ((400, 240, 8), (1280, 720, 4)):
+        with HipRenderer(sc, W, H, seed=SEED, passes_per_launch=24, **kw) as r:
+            want = r.render(24).radiance()[..., :3].copy()
+        for _ in range(cases):
+            k = int(rng.integers(1, 7))
+            cuts = np.sort(rng.choice(np.arange(1, 24), size=k - 1, replace=False)) if k > 1 else np.array([], int)
+            sizes = np.diff(np.concatenate([[0], cuts, [24]])).tolist()
+            ppl = int(rng.choice([0, 1, 3, 4, 5, 8, 16]))
+            with HipRenderer(sc, W, H, seed=SEED, passes_per_launch=ppl, **kw) as r:
+                if rng.random() < 0.5:  # a warmed handle: cost order and parts from the first launch on
+                    r.render(2).wait()
+                    r.reset()
+                for s in sizes:
+                    r.render(int(s))
+                got = r.radiance()[..., :3].copy()
+            assert np.array_equal(bits(got), bits(want)), (mode, W, H, sizes, ppl)
